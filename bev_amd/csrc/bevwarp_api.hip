@@ -1,0 +1,190 @@
+// bevwarp_api.hip -- the extern "C" surface declared in include/bevwarp.h: argument validation,
+// launch geometry, error mapping.  No allocation, no synchronisation, no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bevwarp.h"
+#include "warp_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local char g_hip_error[256] = "";
+
+int hip_fail(hipError_t e) {
+    snprintf(g_hip_error, sizeof(g_hip_error), "%s: %s", hipGetErrorName(e), hipGetErrorString(e));
+    return BEVWARP_ERR_HIP;
+}
+
+bool finite9(const double* m, int n) {
+    for (int i = 0; i < 9 * n; i++)
+        if (!isfinite(m[i])) return false;
+    return true;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Evaluation block width of the reference algorithm (OpenCV WarpPerspectiveInvoker, BLOCK_SZ = 32):
+// bh0 = min(16, h); bw0 = min(1024 / bh0, w).  Values depend on bw0 only.
+int block_width(int dst_w, int dst_h) {
+    const int bh0 = dst_h < 16 ? dst_h : 16;
+    const int bw0 = 1024 / bh0;
+    return bw0 < dst_w ? bw0 : dst_w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bevwarp_version(void) { return BEVWARP_ABI_VERSION; }
+
+const char* bevwarp_strerror(int status) {
+    switch (status) {
+        case BEVWARP_OK: return "ok";
+        case BEVWARP_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or misaligned stride)";
+        case BEVWARP_ERR_UNSUPPORTED: return "unsupported dtype / channel count / interpolation";
+        case BEVWARP_ERR_TOO_LARGE: return "source image side exceeds 32767 px or a frame exceeds 2 GiB";
+        case BEVWARP_ERR_NOT_FINITE: return "homography contains NaN or Inf";
+        case BEVWARP_ERR_HIP: return "HIP runtime error (see bevwarp_last_hip_error)";
+        default: return "unknown status";
+    }
+}
+
+const char* bevwarp_last_hip_error(void) { return g_hip_error; }
+
+int bevwarp_invert_homography(const double* S, double* D, int n) {
+    if (!S || !D || n < 0) return BEVWARP_ERR_BAD_ARG;
+    if (!finite9(S, n)) return BEVWARP_ERR_NOT_FINITE;
+    for (int k = 0; k < n; k++, S += 9, D += 9) {
+        // cv::invert, 3x3 double: cofactors times 1/det, in this evaluation order
+        double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+        if (d == 0.0) {
+            memset(D, 0, 9 * sizeof(double));
+            continue;
+        }
+        d = 1.0 / d;
+        double t[9];
+        t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+        t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+        t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+        t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+        t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+        t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+        t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+        t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+        t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+        memcpy(D, t, sizeof(t));
+    }
+    return BEVWARP_OK;
+}
+
+int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                 int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv,
+                 int m_count, int dtype, int interp, const double* border_value, void* stream) {
+    using namespace bevwarp;
+    if (!src || !dst || !M_inv) return BEVWARP_ERR_BAD_ARG;
+    if (batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_U8 && dtype != BEVWARP_F32) return BEVWARP_ERR_UNSUPPORTED;
+    if (interp != BEVWARP_NEAREST && interp != BEVWARP_LINEAR) return BEVWARP_ERR_UNSUPPORTED;
+    if (channels < 1 || channels > 4) return BEVWARP_ERR_UNSUPPORTED;
+    if (m_count != 1 && m_count != batch) return BEVWARP_ERR_BAD_ARG;
+    const int esz = dtype == BEVWARP_U8 ? 1 : 4;
+    const int64_t pix = (int64_t)channels * esz;
+    if (src_row_stride < src_w * pix || dst_row_stride < dst_w * pix) return BEVWARP_ERR_BAD_ARG;
+    if (batch > 1 && (src_frame_stride < src_h * src_row_stride || dst_frame_stride < dst_h * dst_row_stride)) return BEVWARP_ERR_BAD_ARG;
+    if ((src_row_stride % esz) || (dst_row_stride % esz) || (src_frame_stride % esz) || (dst_frame_stride % esz) ||
+        ((uintptr_t)src % esz) || ((uintptr_t)dst % esz))
+        return BEVWARP_ERR_BAD_ARG;
+    if (src_w > 32767 || src_h > 32767) return BEVWARP_ERR_TOO_LARGE;
+    if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31)) return BEVWARP_ERR_TOO_LARGE;
+    if (batch == 0) return BEVWARP_OK;
+
+    WarpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = (const uint8_t*)src;
+    a.dst = (uint8_t*)dst;
+    a.minv = M_inv;
+    a.src_fs = src_frame_stride;
+    a.src_rs = src_row_stride;
+    a.dst_fs = dst_frame_stride;
+    a.dst_rs = dst_row_stride;
+    a.batch = batch;
+    a.src_h = src_h;
+    a.src_w = src_w;
+    a.dst_h = dst_h;
+    a.dst_w = dst_w;
+    a.m_stride = m_count == 1 ? 0 : 9;
+    a.bw0 = block_width(dst_w, dst_h);
+    a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 16 : 16);
+    if (a.tile_h != 16 && a.tile_h != 32 && a.tile_h != 64) a.tile_h = 16;
+    a.tiles_x = (dst_w + tile_width() - 1) / tile_width();
+    const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
+    a.tiles_per_frame = a.tiles_x * tiles_y;
+    a.total_tiles = (int64_t)batch * a.tiles_per_frame;
+    const int64_t chunk = (a.total_tiles + 7) / 8;
+    if (chunk * 8 > 0x7fffffffLL) return BEVWARP_ERR_TOO_LARGE;
+    a.chunk = (int)chunk;
+    a.lds_bytes = env_int("BEVWARP_LDS_BYTES", dtype == BEVWARP_U8 ? 24 * 1024 : 40 * 1024);
+    if (a.lds_bytes < 0) a.lds_bytes = 0;
+    if (a.lds_bytes > 64 * 1024 - 256) a.lds_bytes = 64 * 1024 - 256;
+    a.lds_bytes &= ~15;
+
+    // staged loads: u8x3 reads 12-byte groups (4-byte aligned), the other formats 16-byte chunks;
+    // both need the row to end on a 4-pixel boundary so a group never crosses into the next row.
+    const bool u8x3 = dtype == BEVWARP_U8 && channels == 3;
+    const int src_align = u8x3 ? 4 : 16;
+    a.src_vec_ok = (src_w % 4 == 0) && ((uintptr_t)src % src_align == 0) && (src_row_stride % src_align == 0) &&
+                   (src_frame_stride % src_align == 0) && a.lds_bytes > 0 && !env_int("BEVWARP_NO_LDS", 0);
+    const int dst_align = u8x3 ? 4 : 16;
+    a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);
+    for (int k = 0; k < 4; k++) {
+        const double b = (border_value && k < channels) ? border_value[k] : 0.0;
+        if (!isfinite(b)) return BEVWARP_ERR_NOT_FINITE;
+        a.bval_f[k] = (float)b;
+        const double r = nearbyint(b);  // saturate_cast<uchar>: round half to even, clamp
+        a.bval_u8[k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    const hipError_t e = launch_warp(a, dtype, channels, interp, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
+int bevwarp_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* M_inv, int m_count,
+                      int interp, void* stream) {
+    if (!touched || !M_inv || batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
+    if (interp != BEVWARP_NEAREST && interp != BEVWARP_LINEAR) return BEVWARP_ERR_UNSUPPORTED;
+    if (m_count != 1 && m_count != batch) return BEVWARP_ERR_BAD_ARG;
+    if (src_w > 32767 || src_h > 32767 || dst_h > 65535 || batch > 65535) return BEVWARP_ERR_TOO_LARGE;
+    if (batch == 0) return BEVWARP_OK;
+    const hipError_t e = bevwarp::launch_footprint(touched, batch, src_h, src_w, dst_h, dst_w, M_inv, m_count == 1 ? 0 : 9,
+                                                   block_width(dst_w, dst_h), interp, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
+int bevwarp_project_points(const void* in, void* out, int64_t n, int dim, const double* H, int dtype, void* stream) {
+    if (!H || n < 0 || (n > 0 && (!in || !out))) return BEVWARP_ERR_BAD_ARG;
+    if (dim != 2 && dim != 3) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_F32 && dtype != BEVWARP_F64) return BEVWARP_ERR_UNSUPPORTED;
+    if (!finite9(H, 1)) return BEVWARP_ERR_NOT_FINITE;
+    const int esz = dtype == BEVWARP_F32 ? 4 : 8;
+    const int need = dim == 2 ? 2 * esz : esz;  // 2-D points move as one 8 / 16 byte unit
+    if (((uintptr_t)in % need) || ((uintptr_t)out % need)) return BEVWARP_ERR_BAD_ARG;
+    const hipError_t e = bevwarp::launch_project_points(in, out, n, dim, H, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
+int bevwarp_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype, void* stream) {
+    if (na < 0 || nb < 0 || a_stride < 5 || b_stride < 5) return BEVWARP_ERR_BAD_ARG;
+    if (na > 0 && nb > 0 && (!a || !b || !out)) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_F32 && dtype != BEVWARP_F64) return BEVWARP_ERR_UNSUPPORTED;
+    if (na > 65535) return BEVWARP_ERR_TOO_LARGE;
+    const hipError_t e = bevwarp::launch_rbox_iou(a, na, a_stride, b, nb, b_stride, out, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// Internal interface between the C ABI (bevwarp_api.hip) and the kernels.  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bevwarp {
+
+constexpr int kNearest = 0;
+constexpr int kLinear = 1;
+
+struct WarpArgs {
+    const uint8_t* src;
+    uint8_t* dst;
+    const double* minv;          // device, inverse matrices
+    int64_t src_fs, src_rs;      // frame / row strides in bytes
+    int64_t dst_fs, dst_rs;
+    int64_t total_tiles;         // batch * tiles_per_frame
+    int batch, src_h, src_w, dst_h, dst_w;
+    int m_stride;                // 9 (one matrix per frame) or 0 (shared)
+    int bw0;                     // evaluation block width of the reference algorithm
+    int tiles_x, tiles_per_frame;
+    int tile_h;                  // 16 or 32 rows per workgroup
+    int chunk;                   // items per XCD: grid = 8 * chunk
+    int lds_bytes;               // dynamic LDS given to the staged region
+    int src_vec_ok;              // source layout admits the aligned staging loads
+    int dst_vec_ok;              // destination layout admits the wide stores
+    float bval_f[4];
+    uint8_t bval_u8[4];
+};
+
+int tile_width();
+int rows_per_pass();
+hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
+hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
+                            int m_stride, int bw0, int interp, hipStream_t stream);
+hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, const double* H, int dtype, hipStream_t stream);
+hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype,
+                           hipStream_t stream);
+
+}  // namespace bevwarp

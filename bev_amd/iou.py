@@ -1,0 +1,36 @@
+"""Device rotated-box IoU: the tracker's iou_batch_rbox (reference bev/tracker/rbox_tracker.py:87-92,
+which calls d3d.box.box2d_iou(.., method="rbox")) as one HIP launch over all N x M pairs."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def rbox_iou(a, b):
+    """a: (N, >=5), b: (M, >=5) CUDA tensors of [x, y, w, h, yaw, ...] (world convention: length h along the
+    heading).  Returns the (N, M) IoU matrix, same dtype."""
+    if not (isinstance(a, torch.Tensor) and a.is_cuda and isinstance(b, torch.Tensor) and b.is_cuda):
+        raise ValueError("rbox_iou needs CUDA (HIP) tensors")
+    if a.dtype != b.dtype or a.dtype not in _DTYPES or a.dim() != 2 or b.dim() != 2 or a.shape[1] < 5 or b.shape[1] < 5:
+        raise ValueError("a, b must be (N, >=5) / (M, >=5) tensors of the same float dtype")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=a.dtype, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    with torch.cuda.device(a.device):
+        st = _lib.load().bevwarp_rbox_iou(a.data_ptr(), a.shape[0], a.shape[1], b.data_ptr(), b.shape[0], b.shape[1],
+                                          out.data_ptr(), _DTYPES[a.dtype], ctypes.c_void_p(stream))
+    _lib.check(st)
+    return out
+
+
+def iou_batch_rbox(bb_test, bb_gt, device="cuda"):
+    """Drop-in for the tracker front-end (rbox_tracker.py:87-92): numpy (N, >=5) x (M, >=5) -> numpy (N, M).
+    The reference adds pi/2 to both yaws before calling d3d; IoU is invariant to that common rotation
+    under this package's rectangle convention, so it is not applied."""
+    ta = torch.from_numpy(np.ascontiguousarray(bb_test[:, :5], dtype=np.float64)).to(device)
+    tb = torch.from_numpy(np.ascontiguousarray(bb_gt[:, :5], dtype=np.float64)).to(device)
+    return rbox_iou(ta, tb).cpu().numpy()

@@ -1,0 +1,148 @@
+"""Device warp: the HIP replacement for `cv2.warpPerspective(img, H_bev_img, (u_size, v_size))`
+(reference call sites vis_homo.py:89, :91; bev/tool/compo.py:38, :46, :47).
+
+    dst = warp_perspective(src, M, (u_size, v_size))            # torch tensors on the GPU, batched
+    dst = warpPerspective(img, M, (u_size, v_size))             # numpy in / numpy out, cv2 call shape
+
+M is the FORWARD map (src px -> dst px) exactly as callers hand it to OpenCV; it is inverted on the
+host with OpenCV's closed form and the inverse is cached on the device (calibrations are static per
+camera).  All pixel work happens in bev_amd/csrc (HIP, gfx950) through the C ABI; nothing here
+falls back to the CPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+INTER_NEAREST = _lib.INTER_NEAREST
+INTER_LINEAR = _lib.INTER_LINEAR
+WARP_INVERSE_MAP = 16  # cv2 flag value
+BORDER_CONSTANT = 0
+
+_DTYPES = {torch.uint8: _lib.U8, torch.float32: _lib.F32}
+
+
+def invert_homography(M):
+    """Host float64 inverse(s) of 3x3 matrices, OpenCV evaluation order.  (..., 3, 3) -> same shape."""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    assert M.shape[-2:] == (3, 3), M.shape
+    out = np.empty_like(M)
+    _lib.check(_lib.load().bevwarp_invert_homography(M.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                                                     int(M.size // 9)))
+    return out
+
+
+_minv_cache = {}
+
+
+def device_inverse(M, device, inverse_given=False):
+    """(n, 3, 3) float64 device tensor of inverse matrices for forward matrices M (cached by value)."""
+    if isinstance(M, torch.Tensor) and M.is_cuda and inverse_given:
+        return M.to(torch.float64).reshape(-1, 3, 3).contiguous()
+    Mh = np.ascontiguousarray(M.detach().cpu().numpy() if isinstance(M, torch.Tensor) else M, dtype=np.float64).reshape(-1, 3, 3)
+    key = (Mh.tobytes(), str(device), bool(inverse_given))
+    hit = _minv_cache.get(key)
+    if hit is None:
+        if len(_minv_cache) > 256:
+            _minv_cache.clear()
+        inv = Mh if inverse_given else invert_homography(Mh)
+        hit = torch.from_numpy(inv).to(device)
+        _minv_cache[key] = hit
+    return hit
+
+
+def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=None, M_inv_device=None):
+    """Batched perspective warp on the GPU.
+
+    src      (B, H, W, C) or (H, W, C) or (H, W) uint8 / float32 CUDA tensor, channels-last, rows contiguous.
+    M        (3, 3) shared or (B, 3, 3) per-frame forward homography (numpy or tensor); with
+             flags | WARP_INVERSE_MAP it is taken as the dst -> src map instead.
+    dsize    (width, height) = (u_size, v_size), as OpenCV.
+    flags    INTER_LINEAR (default) or INTER_NEAREST, optionally | WARP_INVERSE_MAP.
+    out      optional preallocated result; M_inv_device optional (n, 3, 3) f64 CUDA tensor to skip the cache.
+    Returns a tensor shaped like src with (height, width) replaced.  Asynchronous on the current stream."""
+    if not isinstance(src, torch.Tensor) or not src.is_cuda:
+        raise ValueError("warp_perspective needs a CUDA (HIP) tensor; use warpPerspective for numpy images")
+    if src.dtype not in _DTYPES:
+        raise ValueError("unsupported dtype %s (uint8 / float32)" % src.dtype)
+    interp = int(flags) & 7
+    if interp not in (INTER_NEAREST, INTER_LINEAR):
+        raise ValueError("unsupported interpolation flag %d" % interp)
+    shape = tuple(src.shape)
+    s4 = src
+    if src.dim() == 2:
+        s4 = src[None, :, :, None]
+    elif src.dim() == 3:
+        s4 = src[None]
+    elif src.dim() != 4:
+        raise ValueError("src must be (B,H,W,C), (H,W,C) or (H,W)")
+    B, H, W, C = s4.shape
+    if s4.stride(3) != 1 or s4.stride(2) != C:
+        s4 = s4.contiguous()
+    dw, dh = int(dsize[0]), int(dsize[1])
+    esz = s4.element_size()
+    if M_inv_device is None:
+        M_inv_device = device_inverse(M, s4.device, inverse_given=bool(int(flags) & WARP_INVERSE_MAP))
+    n_m = M_inv_device.shape[0]
+    if n_m not in (1, B):
+        raise ValueError("got %d homographies for a batch of %d" % (n_m, B))
+    if out is None:
+        d4 = torch.empty((B, dh, dw, C), dtype=s4.dtype, device=s4.device)
+    else:
+        d4 = out.reshape(B, dh, dw, C)
+        if d4.data_ptr() != out.data_ptr() or d4.stride(3) != 1 or d4.stride(2) != C:
+            raise ValueError("out must be a contiguous-row channels-last tensor")
+    bv = None
+    if border_value is not None:
+        bv = np.ascontiguousarray(np.broadcast_to(np.asarray(border_value, dtype=np.float64), (C,)))
+    stream = torch.cuda.current_stream(s4.device).cuda_stream
+    with torch.cuda.device(s4.device):
+        st = _lib.load().bevwarp_warp(
+            s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C,
+            s4.stride(0) * esz, s4.stride(1) * esz, d4.stride(0) * esz, d4.stride(1) * esz,
+            M_inv_device.data_ptr(), n_m, _DTYPES[s4.dtype], interp,
+            None if bv is None else bv.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(stream))
+    _lib.check(st)
+    if out is not None:
+        return out
+    if len(shape) == 2:
+        return d4[0, :, :, 0]
+    if len(shape) == 3:
+        return d4[0]
+    return d4
+
+
+def footprint(src_hw, M, dsize, batch=None, flags=INTER_LINEAR, device="cuda"):
+    """Exact count of distinct in-bounds source pixels the warp reads, per frame.
+    Returns (counts int64 tensor [n], touched uint8 tensor [n, H, W])."""
+    H, W = int(src_hw[0]), int(src_hw[1])
+    minv = device_inverse(M, torch.device(device), inverse_given=bool(int(flags) & WARP_INVERSE_MAP))
+    n = minv.shape[0] if batch is None else int(batch)
+    touched = torch.zeros((n, H, W), dtype=torch.uint8, device=minv.device)
+    stream = torch.cuda.current_stream(minv.device).cuda_stream
+    with torch.cuda.device(minv.device):
+        st = _lib.load().bevwarp_footprint(touched.data_ptr(), n, H, W, int(dsize[1]), int(dsize[0]), minv.data_ptr(),
+                                           minv.shape[0], int(flags) & 7, ctypes.c_void_p(stream))
+    _lib.check(st)
+    return touched.reshape(n, -1).sum(dim=1, dtype=torch.int64), touched
+
+
+def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0, device="cuda"):
+    """cv2.warpPerspective call shape for numpy images: uploads, warps on the GPU, downloads.
+    (The per-frame PCIe round trip dominates here; batch frames with warp_perspective for throughput.)"""
+    if borderMode != BORDER_CONSTANT:
+        raise ValueError("only BORDER_CONSTANT is implemented (the reference never passes another mode)")
+    img = np.asarray(src)
+    if img.dtype not in (np.uint8, np.float32):
+        raise ValueError("unsupported dtype %s (uint8 / float32)" % img.dtype)
+    t = torch.from_numpy(np.ascontiguousarray(img)).to(device)
+    bv = borderValue
+    if np.ndim(bv) > 0:
+        bv = np.asarray(bv, dtype=np.float64).ravel()[:(1 if img.ndim == 2 else img.shape[2])]
+    res = warp_perspective(t, np.asarray(M, dtype=np.float64), dsize, flags=flags, border_value=bv).cpu().numpy()
+    if dst is not None:
+        dst[...] = res
+        return dst
+    return res

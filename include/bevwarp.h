@@ -1,0 +1,110 @@
+/*
+ * bevwarp.h -- C ABI of libbevwarp.so, the MI355X (gfx950) BEV homography-warp path.
+ *
+ * The reference (minghanz/bev) has no FFI / plugin interface for this path: its pixel work is one
+ * third-party call.  Every entry point below names the reference interface it stands in for
+ * (paths relative to the reference repository root):
+ *
+ *   bevwarp_warp            cv2.warpPerspective(img, H_bev_img, (u_size, v_size))
+ *                             vis_homo.py:89, vis_homo.py:91, bev/tool/compo.py:38,46,47
+ *   bevwarp_invert_homography  the cv::invert(M) step inside that call (M is the forward src->dst map)
+ *   bevwarp_footprint       -- measurement aid (SURVEY.md 8(d) "footprint_px"), no reference twin
+ *   bevwarp_project_points  pts_world_bev(pts_src, H), bev/rbox.py:136-151; rbox_world_img, :221-226;
+ *                             Calib.gen_center_in_world, bev/calib.py:135-138
+ *   bevwarp_rbox_iou        iou_batch_rbox -> d3d.box.box2d_iou(.., method="rbox"),
+ *                             bev/tracker/rbox_tracker.py:87-92 (call site :393-394)
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, enums.  No torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the default stream).
+ *   - All data pointers are DEVICE pointers (HIP) unless marked HOST.  The library never allocates,
+ *     frees or retains caller memory; every call is asynchronous and ordered on `stream`.
+ *   - Images are interleaved HWC, strides in BYTES.  Homographies are 3x3 row-major float64.
+ *   - Return value: BEVWARP_OK (0) or a negative bevwarp_status; bevwarp_strerror() describes it.
+ *     Nothing throws across the ABI.  There is NO CPU fallback: without a HIP device calls fail.
+ *   - Thread-safe and re-entrant: no global mutable state.
+ */
+#ifndef BEVWARP_H
+#define BEVWARP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVWARP_ABI_VERSION 1
+
+typedef enum bevwarp_status {
+    BEVWARP_OK = 0,
+    BEVWARP_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, misaligned or overlapping strides */
+    BEVWARP_ERR_UNSUPPORTED = -2,  /* dtype / channel count / interpolation outside the supported set    */
+    BEVWARP_ERR_TOO_LARGE = -3,    /* source side > 32767 px (fixed-point map range of the algorithm)   */
+    BEVWARP_ERR_NOT_FINITE = -4,   /* homography contains NaN / Inf                                      */
+    BEVWARP_ERR_HIP = -5           /* a HIP runtime call failed; see bevwarp_last_hip_error()            */
+} bevwarp_status;
+
+typedef enum bevwarp_dtype { BEVWARP_U8 = 0, BEVWARP_F32 = 1, BEVWARP_F64 = 2 } bevwarp_dtype;
+
+/* Same numeric values as cv2.INTER_NEAREST / cv2.INTER_LINEAR. */
+typedef enum bevwarp_interp { BEVWARP_NEAREST = 0, BEVWARP_LINEAR = 1 } bevwarp_interp;
+
+int bevwarp_version(void);
+const char *bevwarp_strerror(int status);
+/* Text of the last HIP error seen by the calling thread ("" if none). */
+const char *bevwarp_last_hip_error(void);
+
+/* HOST helper.  M_inv[i] = inverse of M_fwd[i] (n matrices of 9 doubles each) with the closed-form
+ * cofactor / (1/det) evaluation order OpenCV uses for 3x3 doubles; a singular matrix inverts to
+ * all zeros.  Callers upload M_inv to the device and hand it to bevwarp_warp. */
+int bevwarp_invert_homography(const double *M_fwd /*HOST*/, double *M_inv /*HOST*/, int n);
+
+/*
+ * dst[b] = warpPerspective(src[b], M[b], (dst_w, dst_h)) for b in [0, batch), BORDER_CONSTANT.
+ *
+ *   src, dst       device; `channels` interleaved values of `dtype` (BEVWARP_U8 | BEVWARP_F32) per pixel.
+ *                  src and dst must not overlap.
+ *   *_frame_stride bytes between consecutive frames; *_row_stride bytes between rows (>= row bytes).
+ *   M_inv          device; INVERSE (dst px -> src px) matrices, float64, row-major;
+ *                  m_count == batch (one per frame) or 1 (shared by all frames).
+ *   interp         BEVWARP_NEAREST: (X, Y) = round-half-even((x', y') / w'); copy or border.
+ *                  BEVWARP_LINEAR : coordinates quantised to 1/32 px, 4 taps, each tap outside the
+ *                  source replaced by the border value; u8 in 15-bit fixed point, f32 in float.
+ *   border_value   HOST, `channels` doubles, or NULL for 0.
+ *   channels       1..4.   src_w, src_h <= 32767.
+ */
+int bevwarp_warp(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                 int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride,
+                 const double *M_inv, int m_count, int dtype, int interp, const double *border_value /*HOST*/,
+                 void *stream);
+
+/*
+ * Marks every in-bounds source pixel that any tap of any destination pixel of the same warp would
+ * read: touched[b][y][x] = 1 (device bytes, batch x src_h x src_w, caller zero-initialises).
+ * sum(touched) is the exact "footprint_px" term of the algorithmic-bytes figure.
+ */
+int bevwarp_footprint(unsigned char *touched, int batch, int src_h, int src_w, int dst_h, int dst_w,
+                      const double *M_inv, int m_count, int interp, void *stream);
+
+/*
+ * out[i] = dehomogenise(H @ (in[i], 1))            for dim == 2   (n x 2 in, n x 2 out)
+ * out[i] = (H @ in[i]) / (H @ in[i])[2]            for dim == 3   (n x 3 in, n x 3 out)
+ *   in, out  device, contiguous, dtype BEVWARP_F32 | BEVWARP_F64 (arithmetic is float64 either way).
+ *   H        HOST, 9 doubles (copied at call time).  in == out is allowed.
+ */
+int bevwarp_project_points(const void *in, void *out, int64_t n, int dim, const double *H /*HOST*/, int dtype,
+                           void *stream);
+
+/*
+ * out[i][j] = IoU of rotated rectangles a[i], b[j].  Rows are [x, y, w, h, yaw, ...] with
+ * `a_stride` / `b_stride` values per row (>= 5); at yaw 0 the length h lies along +x and the width w
+ * along y (bev/rbox.py:87-95, the "world" convention).  out is na x nb, same dtype.
+ *   dtype BEVWARP_F32 | BEVWARP_F64 (arithmetic is float64).
+ */
+int bevwarp_rbox_iou(const void *a, int na, int a_stride, const void *b, int nb, int b_stride, void *out, int dtype,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVWARP_H */

@@ -1,0 +1,76 @@
+"""Device point projection and rotated IoU against the oracle / the reference's own vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def test_project_points_reference_vectors(golden):
+    from bev_amd.points import project_points
+    g = golden["rbox"]
+    Hm = np.array(g["H_world_img"])
+    for key, out in (("pts2", "pts_world_bev_2"), ("pts3", "pts_world_bev_3")):
+        got = project_points(torch.tensor(g[key], dtype=torch.float64, device="cuda"), Hm).cpu().numpy()
+        np.testing.assert_allclose(got, np.array(g[out]), rtol=1e-12, atol=0)  # outputs of the reference itself
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_project_points_config3(golden, dtype, dim):
+    """configs[2]: 1e7 image points through H_world_img; oracle = C restatement of pts_world_bev."""
+    from bev_amd.points import project_points
+    Hm = np.array(golden["calib_from_vps"]["base"]["H_world_img"])
+    n = 10_000_000 if dim == 2 else 1_000_003
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(0, [1920, 1080], (n, 2))
+    if dim == 3:
+        pts = np.concatenate([pts, rng.uniform(0.5, 2, (n, 1))], axis=1)
+    pts = pts.astype(dtype)
+    t = torch.from_numpy(pts).cuda()
+    got = project_points(t, Hm).cpu().numpy()
+    exp = co.project_points(pts, Hm)
+    if dtype == np.float64:
+        np.testing.assert_allclose(got, exp, rtol=1e-13, atol=0)
+    else:
+        np.testing.assert_array_equal(got, exp)  # same f64 arithmetic, one final rounding to f32
+    # in place, empty, and error behaviour
+    r = project_points(t, Hm, out=t)
+    assert r is t and np.array_equal(t.cpu().numpy(), got)
+    assert project_points(torch.empty((0, dim), dtype=t.dtype, device="cuda"), Hm).shape == (0, dim)
+    with pytest.raises(ValueError):
+        project_points(torch.zeros((4, 4), device="cuda"), Hm)
+    with pytest.raises(ValueError):
+        project_points(torch.zeros((4, 2)), Hm)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rbox_iou_config5(dtype):
+    """configs[4]'s IoU half: 512 detections x 512 tracks."""
+    from bev_amd.iou import iou_batch_rbox, rbox_iou
+    rng = np.random.default_rng(11)
+
+    def boxes(n):
+        return np.stack([rng.uniform(0, 100, n), rng.uniform(0, 100, n), rng.uniform(1.6, 2.2, n), rng.uniform(3.5, 6, n),
+                         rng.uniform(-np.pi, np.pi, n)], axis=1)
+
+    a, b = boxes(512), boxes(512)
+    b[:128] = a[:128] + rng.normal(0, 0.3, (128, 5))  # overlapping pairs
+    exp = co.rbox_iou(a, b)
+    got = rbox_iou(torch.from_numpy(a.astype(dtype)).cuda(), torch.from_numpy(b.astype(dtype)).cuda()).cpu().numpy()
+    assert got.shape == (512, 512) and (np.diag(exp)[:128] > 0.2).all()
+    if dtype == np.float64:
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+    else:
+        np.testing.assert_allclose(got, co.rbox_iou(a.astype(np.float32), b.astype(np.float32)), rtol=0, atol=2e-6)
+    # known answers
+    sq = torch.tensor([[0, 0, 1, 1, 0.0], [0, 0, 1, 1, np.pi / 4], [5, 5, 1, 1, 0.3]], dtype=torch.float64, device="cuda")
+    m = rbox_iou(sq, sq).cpu().numpy()
+    inter = 2 * (np.sqrt(2) - 1)
+    np.testing.assert_allclose(m, [[1, inter / (2 - inter), 0], [inter / (2 - inter), 1, 0], [0, 0, 1]], atol=1e-12)
+    # tracker front-end shape: numpy in, numpy out, extra columns ignored, empty sets
+    dets = np.concatenate([a[:7], np.ones((7, 1))], axis=1)
+    np.testing.assert_allclose(iou_batch_rbox(dets, b[:9]), exp[:7, :9], atol=1e-12)
+    assert rbox_iou(torch.zeros((0, 5), device="cuda"), torch.zeros((3, 5), device="cuda")).shape == (0, 3)

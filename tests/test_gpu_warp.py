@@ -1,0 +1,223 @@
+"""Parity of the HIP path (through the C ABI of include/bevwarp.h) with the CPU oracle.
+Bars (BASELINE.json north_star): uint8 / nearest pixel-for-pixel; float32 bilinear within 1e-5 absolute
+(inputs in [0,1)) -- the kernel keeps the oracle's operation order, so float results are asserted
+bit-identical as well.  Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_oracle as co
+from tests import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def W():
+    from bev_amd import warp
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return warp
+
+
+def run_gpu(W, src_np, M, dsize, interp, **kw):
+    t = torch.from_numpy(np.ascontiguousarray(src_np)).cuda()
+    out = W.warp_perspective(t, M, dsize, flags=interp, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def check(got, exp):
+    if exp.dtype == np.float32:
+        assert np.abs(got - exp).max() <= F32_TOL
+    np.testing.assert_array_equal(got, exp)
+
+
+SHAPES = [
+    ("brno", 1280, 720, 512, 512),      # BASELINE configs[0]
+    ("brno", 1920, 1080, 320, 640),     # a real BrnoCompSpeed BEV size
+    ("keystone", 1920, 1080, 1024, 1024),  # one frame of configs[1]
+    ("keystone", 640, 360, 256, 192),
+    ("brno", 192, 108, 37, 53),         # ragged destination
+    ("keystone", 100, 60, 300, 9),      # height < 16: evaluation blocks are 113 wide
+    ("brno", 64, 36, 70, 1),
+    ("brno", 853, 481, 200, 120),       # source width not a multiple of 4: unstaged path
+]
+
+
+@pytest.mark.parametrize("kind,sw,sh,dw,dh", SHAPES)
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_single_frame_parity(W, kind, sw, sh, dw, dh, dtype, interp):
+    if kind == "brno":
+        M = wl.synth_brno_H(sw, sh, dw, dh) if (sw * 9 == sh * 16) else wl.synth_brno_H(1920, 1080, dw, dh) @ np.diag([1920 / sw, 1080 / sh, 1.0])
+    else:
+        M = wl.keystone_H(sw, sh, dw, dh)
+    src = wl.frame(0, sh, sw, dtype)
+    check(run_gpu(W, src, M, (dw, dh), interp), co.warp_perspective(src, M, (dw, dh), interp))
+
+
+@pytest.mark.parametrize("c", [1, 2, 4])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_channel_counts(W, c, dtype, interp):
+    M = wl.synth_brno_H(640, 360, 160, 200)
+    src = wl.frame(3, 360, 640, dtype, c)
+    check(run_gpu(W, src, M, (160, 200), interp), co.warp_perspective(src, M, (160, 200), interp))
+    g = src[:, :, 0]
+    got = run_gpu(W, g, M, (160, 200), interp)
+    assert got.shape == (200, 160)
+    check(got, co.warp_perspective(g, M, (160, 200), interp))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_batch_per_frame_and_shared_matrix(W, dtype):
+    B, sw, sh, dw, dh = 5, 640, 360, 192, 160
+    base = wl.keystone_H(sw, sh, dw, dh)
+    Ms = np.stack([wl.jitter_H(base, i) for i in range(B)])
+    frames = np.stack([wl.frame(i, sh, sw, dtype) for i in range(B)])
+    t = torch.from_numpy(frames).cuda()
+    got = W.warp_perspective(t, Ms, (dw, dh)).cpu().numpy()
+    for i in range(B):
+        check(got[i], co.warp_perspective(frames[i], Ms[i], (dw, dh)))
+    got = W.warp_perspective(t, base, (dw, dh)).cpu().numpy()
+    for i in range(B):
+        check(got[i], co.warp_perspective(frames[i], base, (dw, dh)))
+    with pytest.raises(ValueError):
+        W.warp_perspective(t, Ms[:3], (dw, dh))
+    # WARP_INVERSE_MAP and preallocated output
+    out = torch.empty((B, dh, dw, 3), dtype=t.dtype, device="cuda")
+    r = W.warp_perspective(t, co.invert3x3(base), (dw, dh), flags=W.INTER_LINEAR | W.WARP_INVERSE_MAP, out=out)
+    assert r is out
+    check(out.cpu().numpy()[2], co.warp_perspective(frames[2], base, (dw, dh)))
+
+
+def test_row_padding_and_frame_views(W):
+    """Strided (row-padded) sources and destinations; a crop view is warped without a copy."""
+    sw, sh, dw, dh = 600, 300, 128, 96
+    M = wl.synth_brno_H(1920, 1080, dw, dh) @ np.diag([1920 / sw, 1080 / sh, 1.0])
+    big = torch.from_numpy(wl.frame(7, sh, sw + 40, np.uint8)).cuda()
+    view = big[:, 8:8 + sw]  # rows keep the pitch of the parent: not 16-byte aligned -> unstaged path
+    assert not view.is_contiguous()
+    got = W.warp_perspective(view, M, (dw, dh)).cpu().numpy()
+    check(got, co.warp_perspective(np.ascontiguousarray(view.cpu().numpy()), M, (dw, dh)))
+    view4 = big[:, 16:16 + 576]
+    got = W.warp_perspective(view4, M, (dw, dh)).cpu().numpy()
+    check(got, co.warp_perspective(np.ascontiguousarray(view4.cpu().numpy()), M, (dw, dh)))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_border_value_identity_translation(W, dtype):
+    src = wl.frame(1, 90, 150, dtype)
+    eye = np.eye(3)
+    np.testing.assert_array_equal(run_gpu(W, src, eye, (100, 60), 1), src[:60, :100])
+    M = np.array([[1, 0, 5.0], [0, 1, -3.0], [0, 0, 1]])
+    for interp in (0, 1):
+        check(run_gpu(W, src, M, (170, 100), interp, border_value=[7, 200.4, 300][:3]),
+              co.warp_perspective(src, M, (170, 100), interp, border_value=[7, 200.4, 300]))
+    M = np.array([[1, 0, 0.5], [0, 1, 0.25], [0, 0, 1.0]])
+    check(run_gpu(W, src, M, (160, 100), 1, border_value=50), co.warp_perspective(src, M, (160, 100), 1, border_value=50))
+    # rotation by 90 degrees and a flip: exact permutations
+    h, w = src.shape[:2]
+    R = np.array([[0, -1, h - 1.0], [1, 0, 0], [0, 0, 1]])
+    np.testing.assert_array_equal(run_gpu(W, src, R, (h, w), 1), np.rot90(src, -1))
+    Fm = np.array([[-1, 0, w - 1.0], [0, 1, 0], [0, 0, 1]])
+    np.testing.assert_array_equal(run_gpu(W, src, Fm, (w, h), 0), src[:, ::-1])
+
+
+def test_degenerate_homographies(W):
+    src = wl.frame(2, 64, 96, np.uint8)
+    # singular forward matrix -> inverse all zeros -> W == 0 everywhere -> every pixel samples (0, 0)
+    check(run_gpu(W, src, np.ones((3, 3)), (40, 30), 1), co.warp_perspective(src, np.ones((3, 3)), (40, 30), 1))
+    # horizon inside the destination: W changes sign across the tile
+    M = np.array([[1.0, 0.2, 3.0], [0.1, 1.0, 2.0], [0.0, 0.02, -0.5]])
+    for interp in (0, 1):
+        check(run_gpu(W, src, M, (128, 96), interp), co.warp_perspective(src, M, (128, 96), interp))
+    # far outside: nothing in bounds
+    T = np.array([[1, 0, 1e6], [0, 1, 0], [0, 0, 1.0]])
+    assert not run_gpu(W, src, T, (64, 64), 1).any()
+    with pytest.raises(ValueError):
+        W.warp_perspective(torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"), np.full((3, 3), np.nan), (8, 8))
+    with pytest.raises(ValueError):
+        W.warp_perspective(torch.zeros((8, 8, 3), dtype=torch.int16, device="cuda"), np.eye(3), (8, 8))
+    with pytest.raises(ValueError):
+        W.warp_perspective(torch.zeros((8, 8, 3), dtype=torch.uint8), np.eye(3), (8, 8))
+
+
+def test_magnification_and_minification_extremes(W):
+    """x8 zoom (tiny source region per tile) and /6 shrink (region exceeds the LDS budget -> unstaged tiles)."""
+    src = wl.frame(4, 720, 1280, np.uint8)
+    Z = np.array([[8.0, 0, -300.0], [0, 8.0, -200.0], [0, 0, 1]])
+    check(run_gpu(W, src, Z, (512, 256), 1), co.warp_perspective(src, Z, (512, 256), 1))
+    S = np.array([[1 / 6.0, 0.01, 1.0], [0.0, 1 / 6.0, 2.0], [0, 1e-5, 1]])
+    for dtype in (np.uint8, np.float32):
+        s = wl.frame(4, 720, 1280, dtype)
+        check(run_gpu(W, s, S, (256, 128), 1), co.warp_perspective(s, S, (256, 128), 1))
+
+
+def test_numpy_cv2_call_shape(W):
+    """bev.warp.warpPerspective(img, H, (u, v)) is the drop-in for the call at vis_homo.py:89."""
+    import bev.warp as bw
+    img = wl.frame(5, 720, 1280, np.uint8)
+    M = wl.synth_brno_H(1280, 720, 512, 512)
+    out = bw.warpPerspective(img, M, (512, 512))
+    assert out.dtype == np.uint8 and out.shape == (512, 512, 3)
+    check(out, co.warp_perspective(img, M, (512, 512)))
+    out = bw.warpPerspective(img, M, (512, 512), flags=bw.INTER_NEAREST, borderValue=(1, 2, 3))
+    check(out, co.warp_perspective(img, M, (512, 512), 0, border_value=[1, 2, 3]))
+
+
+def test_footprint_matches_oracle(W):
+    M = wl.keystone_H(1920, 1080, 1024, 1024)
+    counts, touched = W.footprint((1080, 1920), np.stack([M, wl.jitter_H(M, 1)]), (1024, 1024))
+    n0, t0 = co.footprint((1080, 1920), M, (1024, 1024))
+    assert int(counts[0]) == n0
+    np.testing.assert_array_equal(touched[0].cpu().numpy(), t0)
+    n1, _ = co.footprint((1080, 1920), wl.jitter_H(M, 1), (1024, 1024))
+    assert int(counts[1]) == n1
+    c, _ = W.footprint((360, 640), wl.synth_brno_H(640, 360, 128, 128), (128, 128), flags=W.INTER_NEAREST)
+    assert int(c[0]) == co.footprint((360, 640), wl.synth_brno_H(640, 360, 128, 128), (128, 128), 0)[0]
+
+
+# ---- BASELINE.json full sizes: oracle on sampled frames + size-independent properties -----------------
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_config2_batch32_1080p_to_1024(W, dtype):
+    B, sw, sh, dw, dh = 32, 1920, 1080, 1024, 1024
+    base = wl.keystone_H(sw, sh, dw, dh)
+    Ms = np.stack([wl.jitter_H(base, i) for i in range(B)])
+    frames = torch.empty((B, sh, sw, 3), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device="cuda")
+    host = {}
+    for i in range(B):
+        f = wl.frame(i, sh, sw, dtype)
+        if i in (0, 13, 31):
+            host[i] = f
+        frames[i] = torch.from_numpy(f).cuda()
+    out = W.warp_perspective(frames, Ms, (dw, dh))
+    for i, f in host.items():
+        check(out[i].cpu().numpy(), co.warp_perspective(f, Ms[i], (dw, dh), nthreads=8))
+    # property: same frames, same matrix -> identical outputs, regardless of batch position
+    frames[5] = frames[0]
+    Ms2 = Ms.copy()
+    Ms2[5] = Ms[0]
+    out2 = W.warp_perspective(frames, Ms2, (dw, dh))
+    assert torch.equal(out2[5], out2[0]) and torch.equal(out2[0], out[0])
+    # property: identity homography reproduces the top-left crop for every frame
+    crop = W.warp_perspective(frames, np.eye(3), (dw, dh))
+    assert torch.equal(crop, frames[:, :dh, :dw])
+    if dtype == np.float32:
+        # property: bilinear sampling is linear in the image
+        a, b = frames[:4], frames[4:8]
+        lhs = W.warp_perspective(0.25 * a + 0.5 * b, Ms[:4], (dw, dh))
+        rhs = 0.25 * W.warp_perspective(a, Ms[:4], (dw, dh)) + 0.5 * W.warp_perspective(b, Ms[:4], (dw, dh))
+        assert (lhs - rhs).abs().max().item() < 1e-6
+
+
+def test_config4_single_4k_frame(W):
+    """One frame of configs[3] (3840x2160 -> 2048x2048, uint8); the 8-GPU sharding is covered in test_shard.py."""
+    sw, sh, dw, dh = 3840, 2160, 2048, 2048
+    M = wl.keystone_H(sw, sh, dw, dh)
+    f = wl.frame(0, sh, sw, np.uint8)
+    check(run_gpu(W, f, M, (dw, dh), 1), co.warp_perspective(f, M, (dw, dh), nthreads=8))
+    Mb = wl.synth_brno_H(sw, sh, dw, dh)
+    check(run_gpu(W, f, Mb, (dw, dh), 1), co.warp_perspective(f, Mb, (dw, dh), nthreads=8))
