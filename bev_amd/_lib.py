@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libbevwarp.so")
+LIB_PATH = os.environ.get("BEVWARP_LIB") or os.path.join(_CSRC, "libbevwarp.so")  # override = A/B builds
 
 U8, F32, F64 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1

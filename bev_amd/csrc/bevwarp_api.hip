@@ -40,6 +40,10 @@ int block_width(int dst_w, int dst_h) {
 
 }  // namespace
 
+#ifdef BEVWARP_TIMING
+namespace bevwarp { hipError_t debug_read_phases(unsigned long long* out16, int reset); }
+#endif
+
 extern "C" {
 
 int bevwarp_version(void) { return BEVWARP_ABI_VERSION; }
@@ -121,18 +125,28 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     a.dst_w = dst_w;
     a.m_stride = m_count == 1 ? 0 : 9;
     a.bw0 = block_width(dst_w, dst_h);
-    a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 16 : 16);
-    if (a.tile_h != 16 && a.tile_h != 32 && a.tile_h != 64) a.tile_h = 16;
-    a.tiles_x = (dst_w + tile_width() - 1) / tile_width();
+    // tile = tile_width x tile_h destination pixels per workgroup; the source box of a tile must fit
+    // lds_bytes or the tile is redone in 16-row bands (tunable for experiments through the environment)
+    a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 32 : 16);
+    if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows()) a.tile_h = 16;
+    const int tw = tile_width(dtype);
+    a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
     a.tiles_per_frame = a.tiles_x * tiles_y;
     a.total_tiles = (int64_t)batch * a.tiles_per_frame;
     const int64_t chunk = (a.total_tiles + 7) / 8;
-    if (chunk * 8 > 0x7fffffffLL) return BEVWARP_ERR_TOO_LARGE;
+    if (chunk * 8 > 0x7fffffffLL || dst_w > (1 << 20) || dst_h > (1 << 20)) return BEVWARP_ERR_TOO_LARGE;
     a.chunk = (int)chunk;
-    a.lds_bytes = env_int("BEVWARP_LDS_BYTES", dtype == BEVWARP_U8 ? 24 * 1024 : 40 * 1024);
+    // division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
+    auto magic = [](uint64_t n_max, uint32_t d) -> uint32_t {
+        return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u;
+    };
+    a.tpf_magic = magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
+    a.tx_magic = magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
+    a.bw0_magic = magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
+    a.lds_bytes = env_int("BEVWARP_LDS_BYTES", 32 * 1024);
     if (a.lds_bytes < 0) a.lds_bytes = 0;
-    if (a.lds_bytes > 64 * 1024 - 256) a.lds_bytes = 64 * 1024 - 256;
+    if (a.lds_bytes > 60 * 1024) a.lds_bytes = 60 * 1024;
     a.lds_bytes &= ~15;
 
     // staged loads: u8x3 reads 12-byte groups (4-byte aligned), the other formats 16-byte chunks;
@@ -186,5 +200,9 @@ int bevwarp_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb,
     const hipError_t e = bevwarp::launch_rbox_iou(a, na, a_stride, b, nb, b_stride, out, dtype, (hipStream_t)stream);
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
+
+#ifdef BEVWARP_TIMING
+int bevwarp_debug_phases(unsigned long long* out16, int reset) { return (int)bevwarp::debug_read_phases(out16, reset); }
+#endif
 
 }  // extern "C"

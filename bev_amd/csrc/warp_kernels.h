@@ -7,6 +7,7 @@ namespace bevwarp {
 
 constexpr int kNearest = 0;
 constexpr int kLinear = 1;
+constexpr int kMaxTileH = 64;  // rows of one workgroup's tile (multiple of 16)
 
 struct WarpArgs {
     const uint8_t* src;
@@ -14,12 +15,13 @@ struct WarpArgs {
     const double* minv;          // device, inverse matrices
     int64_t src_fs, src_rs;      // frame / row strides in bytes
     int64_t dst_fs, dst_rs;
-    int64_t total_tiles;         // batch * tiles_per_frame
+    int64_t total_tiles;         // batch * tiles_per_frame (< 2^31)
+    uint32_t tpf_magic, tx_magic, bw0_magic;  // floor(2^32 / d) + 1 for d = tiles_per_frame, tiles_x, bw0; 0 = divide
     int batch, src_h, src_w, dst_h, dst_w;
     int m_stride;                // 9 (one matrix per frame) or 0 (shared)
     int bw0;                     // evaluation block width of the reference algorithm
     int tiles_x, tiles_per_frame;
-    int tile_h;                  // 16 or 32 rows per workgroup
+    int tile_h;                  // 16, 32, 48 or 64 rows per workgroup
     int chunk;                   // items per XCD: grid = 8 * chunk
     int lds_bytes;               // dynamic LDS given to the staged region
     int src_vec_ok;              // source layout admits the aligned staging loads
@@ -28,8 +30,8 @@ struct WarpArgs {
     uint8_t bval_u8[4];
 };
 
-int tile_width();
-int rows_per_pass();
+int tile_width(int dtype);
+int band_rows();
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);

@@ -1,22 +1,27 @@
 // warp_kernels.hip -- batched BEV homography warp for MI355X (gfx950, wave64).  See DESIGN.md.
 //
 // Replaces the per-frame cv2.warpPerspective call of the reference (vis_homo.py:89,91;
-// bev/tool/compo.py:38,46,47).  One workgroup (256 threads = 4 waves) produces one 64 x TH tile of
-// one BEV frame:
-//   1. four lanes map the tile's corner pixels; their source bounding box (+ tap margin) is the
-//      tile's source region,
+// bev/tool/compo.py:38,46,47).  One workgroup (256 threads = 4 waves) produces one TW x TH tile of
+// one BEV frame (TW = 64 for 8-bit pixels, 32 for float pixels):
+//   1. four lanes map the tile's corner pixels; their source bounding box (+ margin) is the tile's
+//      source region; one wave tabulates the per-row terms of the homography (M01*y+M02, ...),
 //   2. the region is staged into LDS with coalesced row loads (u8x3 is widened to 4 B / pixel so a
 //      tap is one aligned dword; other formats keep their natural layout, 16 B per load),
-//   3. every lane owns 4 consecutive BEV pixels of one row: it evaluates the inverse homography in
-//      float64 with the operation order of the reference algorithm (bit-exact coordinates), samples
-//      from LDS and writes 12 / 48 contiguous bytes.
-// Pixels whose taps leave the staged region (image border, degenerate tiles) take a per-lane path
-// that reads global memory with per-tap bounds checks; tiles whose region does not fit the LDS
-// budget, or whose layout is not load-aligned, use that path for every pixel.
+//   3. every lane owns PPL consecutive BEV pixels of one row.  Coordinates are float64.  The fast
+//      path replaces the IEEE division by rcp + Newton (one reciprocal shared by the lane's pixels)
+//      and rounds through the float64 mantissa; it is provably equal to the reference's rounding
+//      chain unless the coordinate lies within 2^-19 of a rounding tie -- those pixels (and anything
+//      non-finite or far outside) re-run the exact chain, operation for operation.
+//   4. taps come from LDS; 8-bit blending is exact integer arithmetic on v_dot4_u32_u8.
+// Pixels whose taps leave the staged region (image border) read global memory with per-tap bounds
+// checks; tiles whose region exceeds the LDS budget are processed in 16-row bands, and as a last
+// resort unstaged.
 //
-// No MFMA: this is a gather, bounded by HBM bandwidth and by the float64 coordinate chain.
+// No MFMA: this is a gather.  The 8-bit kernel is bound by vector-ALU issue (float64 coordinate
+// chain + blending), the float kernel by HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "warp_kernels.h"
 
@@ -26,12 +31,14 @@ namespace bevwarp {
 namespace {
 
 constexpr int kWG = 256;
-constexpr int kLX = 16;                  // lanes along x inside a wave
-constexpr int kLY = 4;                   // lanes along y inside a wave
-constexpr int kPPL = 4;                  // consecutive pixels per lane
-constexpr int kTileW = kLX * kPPL;       // 64 = block width of the reference algorithm for h >= 16
-constexpr int kRowsPerPass = kLY * (kWG / 64);  // 16 rows per workgroup pass
+constexpr int kLX = 16;                          // lanes along x inside a wave
+constexpr int kLY = 4;                           // lanes along y inside a wave
+constexpr int kBandRows = kLY * (kWG / 64);      // 16 rows per workgroup pass
 constexpr int kInterBits = 5;
+constexpr int kRowTabBytes = kMaxTileH * 3 * 8;  // per-row X0, Y0, W0 at the head of dynamic LDS
+
+template <typename T>
+constexpr int pixels_per_lane() { return sizeof(T) == 1 ? 4 : 2; }
 
 // LDS bytes per pixel: u8x3 is widened to 4, everything else is stored as is.
 template <typename T, int C>
@@ -44,9 +51,14 @@ struct U3 {
     uint32_t x, y, z;
 };
 
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t d) {
+    // magic = floor(2^32 / d) + 1, exact while n * d < 2^32 (host guarantees); magic == 0 -> plain division
+    return magic ? __umulhi(n, magic) : n / d;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// Coordinate chain (float64, no contraction).  M = inverse matrix, bx = left edge of the 64-wide
-// evaluation block the pixel belongs to, x1 = x - bx.
+// Exact coordinate chain (float64, no contraction): the reference algorithm operation for operation.
+// M = inverse matrix, bx = left edge of the evaluation block the pixel belongs to, x1 = x - bx.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void row_terms(const double* __restrict__ M, int bx, int y, double& X0, double& Y0, double& W0) {
     const double dbx = (double)bx, dy = (double)y;
@@ -63,17 +75,41 @@ __device__ __forceinline__ int round_sat(double v) {
 }
 
 template <int INTERP>
-__device__ __forceinline__ void map_pixel(double X0, double Y0, double W0, double mx, double my, double mw, int& X, int& Y,
-                                          double* w_out = nullptr) {
-    double W = W0 + mw;
-    if (w_out) *w_out = W;
-    W = (W != 0.0) ? ((INTERP == kLinear ? 32.0 : 1.0) / W) : 0.0;
-    X = round_sat((X0 + mx) * W);
-    Y = round_sat((Y0 + my) * W);
+__device__ __forceinline__ void map_pixel_exact(double Xn, double Yn, double W, int& X, int& Y) {
+    W = (W != 0.0) ? ((INTERP == kLinear ? 32.0 : 1.0) / W) : 0.0;  // IEEE division
+    X = round_sat(Xn * W);
+    Y = round_sat(Yn * W);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Blending.  u8: 15-bit fixed point of the reference == exact integer form below
+// Fast coordinate path.  r ~= 1/W to 2^-48; p = Xn * r; t = p * 2^s + (1.5 * 2^52 + 2^19) puts
+// V = round(fX * 2^20 + 2^19) into the mantissa (fX = coordinate in output units, 1/32 px for
+// bilinear).  X = V >> 20 equals rne(fX_exact) whenever the low 20 bits of V are not within 2 of a
+// wrap (|fX' - fX| <= 2^22 * 2^-47 << 2^-20 for |fX| < 2^22).  Returns false when the exact chain
+// must decide (tie window, |fX| >= 2^22, NaN / Inf, W == 0).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_newton(double w) {
+    double r = __builtin_amdgcn_rcp(w);  // v_rcp_f64: relative error 2^-24.4 (measured)
+    r = __builtin_fma(__builtin_fma(-w, r, 1.0), r, r);  // -> 2^-48.7
+    return r;
+}
+
+template <int INTERP>
+__device__ __forceinline__ bool round_fast(double p, int& X) {
+    constexpr double kScale = INTERP == kLinear ? 33554432.0 /* 32 * 2^20 */ : 1048576.0 /* 2^20 */;
+    constexpr double kMagic = 6755399441055744.0 + 524288.0;  // 1.5 * 2^52 + 2^19
+    const double t = __builtin_fma(p, kScale, kMagic);
+    const uint32_t lo = (uint32_t)__double2loint(t), hi = (uint32_t)__double2hiint(t);
+    // bits 20..51 of the mantissa field hold (V >> 20) + 2^31 (the 2^51 of the magic): flip the top bit
+    X = (int)(__builtin_amdgcn_alignbit(hi, lo, 20) ^ 0x80000000u);
+    const bool tie_window = ((lo + 2u) & 0xfffffu) < 4u;
+    // |fX| < 2^22  <=>  |V| < 2^42 + ..: the high dword stays within 0x400 of the magic's
+    const bool in_range = (hi + 0x400u - 0x43380000u) < 0x800u;
+    return in_range && !tie_window;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Blending.  u8: 15-bit fixed point of the reference == exact integer form
 //   (sum_i p_i * w_i * 32 + 2^14) >> 15  ==  (wy0 * (wx0 p00 + wx1 p01) + wy1 * (wx0 p10 + wx1 p11) + 512) >> 10
 // f32: float weights (1-fy)(1-fx).. (exact multiples of 1/1024), 4 products summed left to right.
 // ---------------------------------------------------------------------------------------------------
@@ -84,19 +120,62 @@ __device__ __forceinline__ uint32_t blend_u8(uint32_t p00, uint32_t p01, uint32_
     return (h0 * wy0 + h1 * wy1 + 512u) >> 10;
 }
 
-__device__ __forceinline__ float blend_f32(float p00, float p01, float p10, float p11, int fx, int fy) {
+__device__ __forceinline__ float blend_f32(float p00, float p01, float p10, float p11, float w00, float w01, float w10, float w11) {
+    return ((p00 * w00 + p01 * w01) + p10 * w10) + p11 * w11;
+}
+
+__device__ __forceinline__ void weights_f32(int fx, int fy, float& w00, float& w01, float& w10, float& w11) {
     const float s = 1.0f / 32.0f;
     const float tx1 = (float)fx * s, ty1 = (float)fy * s;
     const float tx0 = 1.0f - tx1, ty0 = 1.0f - ty1;
-    return ((p00 * (ty0 * tx0) + p01 * (ty0 * tx1)) + p10 * (ty1 * tx0)) + p11 * (ty1 * tx1);
+    w00 = ty0 * tx0;
+    w01 = ty0 * tx1;
+    w10 = ty1 * tx0;
+    w11 = ty1 * tx1;
 }
 
+// Packed 8-bit blend of up to 4 channels: p?? are pixels with channel k in byte k.  Horizontal sums
+// with v_dot4_u32_u8 (weights 32-fx, fx <= 32), vertical with 24-bit mads scaled by 64 so that the
+// result byte sits in bits 16..23:  ((h0*wy0 + h1*wy1) * 64 + 2^15) >> 16 == (S + 512) >> 10.
+template <int C>
+__device__ __forceinline__ uint32_t blend_u8_packed(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
+    const uint32_t wlo = fx * 255u + 32u;         // bytes (32 - fx, fx, 0, 0)
+    const uint32_t whi = wlo << 16;               // bytes (0, 0, 32 - fx, fx)
+    const uint32_t wy1 = fy << 6, wy0 = 2048u - wy1;
+    // (a.k, b.k, a.k', b.k') for channel pairs (0,1) and (2,3)
+    const uint32_t t01 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
+    const uint32_t b01 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
+    uint32_t s[4];
+    s[0] = __builtin_amdgcn_udot4(t01, wlo, 0u, false) * wy0 + __builtin_amdgcn_udot4(b01, wlo, 0u, false) * wy1 + 32768u;
+    if (C > 1) s[1] = __builtin_amdgcn_udot4(t01, whi, 0u, false) * wy0 + __builtin_amdgcn_udot4(b01, whi, 0u, false) * wy1 + 32768u;
+    if (C > 2) {
+        const uint32_t t23 = __builtin_amdgcn_perm(p01, p00, 0x07030602u);
+        const uint32_t b23 = __builtin_amdgcn_perm(p11, p10, 0x07030602u);
+        s[2] = __builtin_amdgcn_udot4(t23, wlo, 0u, false) * wy0 + __builtin_amdgcn_udot4(b23, wlo, 0u, false) * wy1 + 32768u;
+        if (C > 3) s[3] = __builtin_amdgcn_udot4(t23, whi, 0u, false) * wy0 + __builtin_amdgcn_udot4(b23, whi, 0u, false) * wy1 + 32768u;
+    }
+    // gather byte 2 of every sum
+    uint32_t out = (C > 1) ? __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u) : ((s[0] >> 16) & 0xffu);
+    if (C == 3) out = __builtin_amdgcn_perm(s[2], out, 0x0c060100u);
+    if (C == 4) out = __builtin_amdgcn_perm(__builtin_amdgcn_perm(s[3], s[2], 0x06020c0cu), out, 0x07060100u);
+    return out;
+}
+
+// What the border / fallback sampler needs of the source frame, by value (taking the address of the
+// kernel-argument struct would push it to scratch).
+struct SrcView {
+    const uint8_t* frame;
+    int64_t rs;
+    int w, h;
+    float bf[4];
+    uint32_t bu;  // border bytes packed
+};
 template <typename T>
-__device__ __forceinline__ T border_of(const WarpArgs& a, int k);
+__device__ __forceinline__ T border_of(const SrcView& a, int k);
 template <>
-__device__ __forceinline__ uint8_t border_of<uint8_t>(const WarpArgs& a, int k) { return a.bval_u8[k]; }
+__device__ __forceinline__ uint8_t border_of<uint8_t>(const SrcView& a, int k) { return (uint8_t)(a.bu >> (8 * k)); }
 template <>
-__device__ __forceinline__ float border_of<float>(const WarpArgs& a, int k) { return a.bval_f[k]; }
+__device__ __forceinline__ float border_of<float>(const SrcView& a, int k) { return a.bf[k]; }
 
 // A pixel in registers: u8 pixels travel packed in one dword (channel k in byte k, unused bytes 0),
 // f32 pixels as C floats.  (A uint8_t[C] array would be demoted to scratch memory.)
@@ -111,12 +190,13 @@ struct Pixel<uint8_t, C> {
 
 // One pixel straight from global memory with per-tap bounds checks (border, fallback tiles).
 template <typename T, int C, int INTERP>
-__device__ Pixel<T, C> sample_global(const WarpArgs& a, const uint8_t* __restrict__ frame, int X, int Y) {
+__device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, int Y) {
+    const uint8_t* __restrict__ frame = a.frame;
     Pixel<T, C> out;
     if constexpr (sizeof(T) == 1) out.packed = 0;
     if (INTERP == kNearest) {
-        const bool in = (unsigned)X < (unsigned)a.src_w && (unsigned)Y < (unsigned)a.src_h;
-        const T* p = reinterpret_cast<const T*>(frame + (int64_t)Y * a.src_rs) + (int64_t)X * C;
+        const bool in = (unsigned)X < (unsigned)a.w && (unsigned)Y < (unsigned)a.h;
+        const T* p = reinterpret_cast<const T*>(frame + (int64_t)Y * a.rs) + (int64_t)X * C;
 #pragma unroll
         for (int k = 0; k < C; k++) {
             const T v = in ? p[k] : border_of<T>(a, k);
@@ -128,10 +208,12 @@ __device__ Pixel<T, C> sample_global(const WarpArgs& a, const uint8_t* __restric
         return out;
     }
     const int sx = X >> kInterBits, sy = Y >> kInterBits, fx = X & 31, fy = Y & 31;
-    const bool xin0 = (unsigned)sx < (unsigned)a.src_w, xin1 = (unsigned)(sx + 1) < (unsigned)a.src_w;
-    const bool yin0 = (unsigned)sy < (unsigned)a.src_h, yin1 = (unsigned)(sy + 1) < (unsigned)a.src_h;
-    const T* r0 = reinterpret_cast<const T*>(frame + (int64_t)sy * a.src_rs) + (int64_t)sx * C;
-    const T* r1 = reinterpret_cast<const T*>(frame + (int64_t)(sy + 1) * a.src_rs) + (int64_t)sx * C;
+    const bool xin0 = (unsigned)sx < (unsigned)a.w, xin1 = (unsigned)(sx + 1) < (unsigned)a.w;
+    const bool yin0 = (unsigned)sy < (unsigned)a.h, yin1 = (unsigned)(sy + 1) < (unsigned)a.h;
+    const T* r0 = reinterpret_cast<const T*>(frame + (int64_t)sy * a.rs) + (int64_t)sx * C;
+    const T* r1 = reinterpret_cast<const T*>(frame + (int64_t)(sy + 1) * a.rs) + (int64_t)sx * C;
+    float w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+    if constexpr (sizeof(T) == 4) weights_f32(fx, fy, w00, w01, w10, w11);
 #pragma unroll
     for (int k = 0; k < C; k++) {
         const T b = border_of<T>(a, k);
@@ -142,7 +224,7 @@ __device__ Pixel<T, C> sample_global(const WarpArgs& a, const uint8_t* __restric
         if constexpr (sizeof(T) == 1)
             out.packed |= blend_u8(v00, v01, v10, v11, fx, fy) << (8 * k);
         else
-            out.v[k] = blend_f32(v00, v01, v10, v11, fx, fy);
+            out.v[k] = blend_f32(v00, v01, v10, v11, w00, w01, w10, w11);
     }
     return out;
 }
@@ -158,12 +240,7 @@ __device__ __forceinline__ Pixel<T, C> sample_lds(const uint8_t* __restrict__ ld
             out.packed = l[px];
             return out;
         }
-        const uint32_t p00 = l[px], p01 = l[px + 1], p10 = l[px + pitch_px], p11 = l[px + pitch_px + 1];
-        out.packed = 0;
-#pragma unroll
-        for (int k = 0; k < C; k++)
-            out.packed |= blend_u8((p00 >> (8 * k)) & 0xffu, (p01 >> (8 * k)) & 0xffu, (p10 >> (8 * k)) & 0xffu,
-                                   (p11 >> (8 * k)) & 0xffu, fx, fy) << (8 * k);
+        out.packed = blend_u8_packed<C>(l[px], l[px + 1], l[px + pitch_px], l[px + pitch_px + 1], (uint32_t)fx, (uint32_t)fy);
     } else {
         const float* l0 = reinterpret_cast<const float*>(lds + (size_t)px * PB);
         if (INTERP == kNearest) {
@@ -178,68 +255,71 @@ __device__ __forceinline__ Pixel<T, C> sample_lds(const uint8_t* __restrict__ ld
             t0[k] = l0[k];
             t1[k] = l1[k];
         }
+        float w00, w01, w10, w11;
+        weights_f32(fx, fy, w00, w01, w10, w11);
 #pragma unroll
-        for (int k = 0; k < C; k++) out.v[k] = blend_f32(t0[k], t0[k + C], t1[k], t1[k + C], fx, fy);
+        for (int k = 0; k < C; k++) out.v[k] = blend_f32(t0[k], t0[k + C], t1[k], t1[k + C], w00, w01, w10, w11);
     }
     return out;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Region staging.  rows x npx pixels starting at (ax0, ry0); ax0 and npx are multiples of 4.
+// A row is covered by the smallest power-of-two group of lanes (16 / 32 / 64) that holds its
+// load units, so a 256-thread pass stages 16 / 8 / 4 rows with coalesced contiguous loads.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int C>
 __device__ __forceinline__ void stage_region(const WarpArgs& a, const uint8_t* __restrict__ frame, uint8_t* __restrict__ lds, int ax0,
                                              int ry0, int rows, int npx, int tid) {
-    if constexpr (sizeof(T) == 1 && C == 3) {
-        // 4 pixels = 12 source bytes (3 dwords, 4-byte aligned) -> 4 LDS dwords B|G|R|0
-        const int gpr = npx >> 2;  // groups per row
-        const int total = rows * gpr;
-        const int step_r = kWG / gpr, step_q = kWG % gpr;
-        int r = tid / gpr, q = tid % gpr;
-        const uint8_t* base = frame + (int64_t)ry0 * a.src_rs + (int64_t)ax0 * 3;
-        uint4* l = reinterpret_cast<uint4*>(lds);
-        for (int g = tid; g < total; g += kWG) {
-            const U3 v = *reinterpret_cast<const U3*>(base + (int64_t)r * a.src_rs + q * 12);
-            uint4 o;
-            o.x = v.x & 0x00ffffffu;
-            o.y = __builtin_amdgcn_alignbyte(v.y, v.x, 3) & 0x00ffffffu;
-            o.z = __builtin_amdgcn_alignbyte(v.z, v.y, 2) & 0x00ffffffu;
-            o.w = v.z >> 8;
-            l[r * gpr + q] = o;
-            r += step_r;
-            q += step_q;
-            if (q >= gpr) {
-                q -= gpr;
-                r++;
+    constexpr bool kWiden = sizeof(T) == 1 && C == 3;
+    constexpr int PB = lds_pixel_bytes<T, C>();
+    const int upr = kWiden ? (npx >> 2) : ((npx * PB) >> 4);  // load units per row (12 B -> 16 B, or 16 B)
+    const int lg = upr <= 16 ? 4 : (upr <= 32 ? 5 : 6);
+    const int lanes = 1 << lg, rstep = kWG >> lg;
+    const int q0 = tid & (lanes - 1);
+    const uint8_t* base = frame + (int64_t)ry0 * a.src_rs + (int64_t)ax0 * (kWiden ? 3 : PB);
+    uint4* l = reinterpret_cast<uint4*>(lds);
+    using Unit = typename std::conditional<kWiden, U3, uint4>::type;
+    constexpr int UB = kWiden ? 12 : 16;
+    // Memory-level parallelism: a thread first ISSUES up to kBatch loads (its rows of kBatch consecutive
+    // passes), then widens / writes them to LDS -- one exposed HBM latency per batch instead of per load.
+    // Branch-free inside a batch (rows past the end are clamped to the last row: a redundant, identical
+    // load + store) so that the compiler emits the loads back to back instead of load / wait / write chains.
+    constexpr int kBatch = 4;
+    const int last = rows - 1;
+    for (int q = q0; q < upr; q += lanes) {
+        for (int r0 = tid >> lg; r0 < rows; r0 += rstep * kBatch) {
+            Unit v[kBatch];
+            int rr[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; i++) {
+                rr[i] = min(r0 + i * rstep, last);
+                v[i] = *reinterpret_cast<const Unit*>(base + (int64_t)rr[i] * a.src_rs + q * UB);
             }
-        }
-    } else {
-        constexpr int PB = lds_pixel_bytes<T, C>();
-        const int cpr = (npx * PB) >> 4;  // 16-byte chunks per row
-        const int total = rows * cpr;
-        const int step_r = kWG / cpr, step_q = kWG % cpr;
-        int r = tid / cpr, q = tid % cpr;
-        const uint8_t* base = frame + (int64_t)ry0 * a.src_rs + (int64_t)ax0 * PB;
-        uint4* l = reinterpret_cast<uint4*>(lds);
-        for (int g = tid; g < total; g += kWG) {
-            l[r * cpr + q] = *reinterpret_cast<const uint4*>(base + (int64_t)r * a.src_rs + q * 16);
-            r += step_r;
-            q += step_q;
-            if (q >= cpr) {
-                q -= cpr;
-                r++;
+#pragma unroll
+            for (int i = 0; i < kBatch; i++) {
+                if constexpr (kWiden) {
+                    uint4 o;
+                    o.x = v[i].x & 0x00ffffffu;
+                    o.y = __builtin_amdgcn_alignbyte(v[i].y, v[i].x, 3) & 0x00ffffffu;
+                    o.z = __builtin_amdgcn_alignbyte(v[i].z, v[i].y, 2) & 0x00ffffffu;
+                    o.w = v[i].z >> 8;
+                    l[rr[i] * upr + q] = o;
+                } else {
+                    l[rr[i] * upr + q] = v[i];
+                }
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Output of one lane: kPPL pixels, contiguous in the row (12 B for u8x3, 48 B for f32x3).
+// Output of one lane: PPL pixels, contiguous in the row (12 B for u8x3, 24 B for f32x3).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int C>
+template <typename T, int C, int PPL>
 __device__ __forceinline__ void store_pixels(const WarpArgs& a, uint8_t* __restrict__ drow, int x, int nvalid, const Pixel<T, C>* v) {
     T* d = reinterpret_cast<T*>(drow) + (int64_t)x * C;
-    if (nvalid == kPPL && a.dst_vec_ok) {
+    if (nvalid == PPL && a.dst_vec_ok) {
         if constexpr (sizeof(T) == 1 && C == 3) {
             U3 o;
             o.x = v[0].packed | (v[1].packed << 24);
@@ -252,19 +332,24 @@ __device__ __forceinline__ void store_pixels(const WarpArgs& a, uint8_t* __restr
             *reinterpret_cast<uint4*>(d) = make_uint4(v[0].packed, v[1].packed, v[2].packed, v[3].packed);
             return;
         }
-        if constexpr (sizeof(T) == 4) {  // 4 pixels x C floats = C chunks of 16 B
-            float f[kPPL * C];
+        if constexpr (sizeof(T) == 4) {  // 2 pixels x C floats = C units of 8 B
+            float f[PPL * C];
 #pragma unroll
-            for (int j = 0; j < kPPL; j++)
+            for (int j = 0; j < PPL; j++)
 #pragma unroll
                 for (int k = 0; k < C; k++) f[j * C + k] = v[j].v[k];
+            if constexpr ((PPL * C) % 4 == 0) {
 #pragma unroll
-            for (int k = 0; k < C; k++) reinterpret_cast<float4*>(d)[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+                for (int k = 0; k < PPL * C / 4; k++) reinterpret_cast<float4*>(d)[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPL * C / 2; k++) reinterpret_cast<float2*>(d)[k] = make_float2(f[2 * k], f[2 * k + 1]);
+            }
             return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < kPPL; j++) {
+    for (int j = 0; j < PPL; j++) {
         if (j >= nvalid) break;
 #pragma unroll
         for (int k = 0; k < C; k++) {
@@ -276,19 +361,174 @@ __device__ __forceinline__ void store_pixels(const WarpArgs& a, uint8_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One lane's PPL pixels of one row when the whole band samples strictly inside its staged region
+// ("interior": no border taps, W of one sign and sane magnitude, one evaluation block, full lanes).
+// Straight-line code: all LDS reads of the lane's pixels are issued before the blends.
+//   rt      LDS row terms X0, Y0, W0 of this row
+//   raw*    coordinates as they come out of the mantissa: X + 2^31 (top bit flipped); the shifts
+//           below keep working on that biased form and `idx_bias` absorbs the offsets modulo 2^32.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int C, int INTERP, int PPL>
+__device__ __forceinline__ void row_fast(const double* __restrict__ rt, const double (&mx)[PPL], const double (&my)[PPL],
+                                         const double (&mw)[PPL], const uint8_t* __restrict__ lds_px, uint32_t npx, uint32_t idx_bias,
+                                         uint8_t* __restrict__ dptr) {
+    constexpr double kScale = INTERP == kLinear ? 33554432.0 /* 32 * 2^20 */ : 1048576.0 /* 2^20 */;
+    constexpr double kMagic = 6755399441055744.0 + 524288.0;  // 1.5 * 2^52 + 2^19
+    const double X0 = rt[0], Y0 = rt[1], W0 = rt[2];
+    double W[PPL], r[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) W[j] = W0 + mw[j];
+    // one reciprocal per lane: 1 / (W0 W1 [W2 W3]), scaled by 2^s (exact), then back-substitution
+    if constexpr (PPL == 4) {
+        const double p01 = W[0] * W[1], p23 = W[2] * W[3];
+        const double inv = rcp_newton(p01 * p23) * kScale;
+        const double i01 = inv * p23, i23 = inv * p01;
+        r[0] = i01 * W[1];
+        r[1] = i01 * W[0];
+        r[2] = i23 * W[3];
+        r[3] = i23 * W[2];
+    } else {
+        const double inv = rcp_newton(W[0] * W[1]) * kScale;
+        r[0] = inv * W[1];
+        r[1] = inv * W[0];
+    }
+    uint32_t rawX[PPL], rawY[PPL];
+    uint32_t tie = 0xffffffffu;  // min over the lane's coordinates of the distance-to-tie field
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        const double tx = (X0 + mx[j]) * r[j] + kMagic, ty = (Y0 + my[j]) * r[j] + kMagic;
+        const uint32_t lox = (uint32_t)__double2loint(tx), loy = (uint32_t)__double2loint(ty);
+        rawX[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(tx), lox, 20);
+        rawY[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(ty), loy, 20);
+        tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+    }
+    if (tie == 0) {  // rare: within 2^-19 of a rounding tie (or NaN / Inf, whose low dword is 0): exact chain
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const double tx = (X0 + mx[j]) * r[j] + kMagic, ty = (Y0 + my[j]) * r[j] + kMagic;
+            if ((((uint32_t)__double2loint(tx) + 2u) & 0xffffcu) == 0 || (((uint32_t)__double2loint(ty) + 2u) & 0xffffcu) == 0) {
+                int X, Y;
+                map_pixel_exact<INTERP>(X0 + mx[j], Y0 + my[j], W[j], X, Y);
+                rawX[j] = (uint32_t)X ^ 0x80000000u;
+                rawY[j] = (uint32_t)Y ^ 0x80000000u;
+            }
+        }
+    }
+    constexpr int SH = INTERP == kLinear ? kInterBits : 0;
+    constexpr int PB = lds_pixel_bytes<T, C>();
+    Pixel<T, C> v[PPL];
+    if constexpr (sizeof(T) == 1) {
+        const uint32_t* l = reinterpret_cast<const uint32_t*>(lds_px);
+        uint32_t p00[PPL], p01[PPL], p10[PPL], p11[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const uint32_t idx = (rawY[j] >> SH) * npx + (rawX[j] >> SH) + idx_bias;
+            p00[j] = l[idx];
+            if (INTERP == kLinear) {
+                p01[j] = l[idx + 1];
+                p10[j] = l[idx + npx];
+                p11[j] = l[idx + npx + 1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; j++)
+            v[j].packed = INTERP == kLinear ? blend_u8_packed<C>(p00[j], p01[j], p10[j], p11[j], rawX[j] & 31u, rawY[j] & 31u) : p00[j];
+    } else {
+        float t0[PPL][2 * C], t1[PPL][2 * C];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const uint32_t idx = (rawY[j] >> SH) * npx + (rawX[j] >> SH) + idx_bias;
+            const float* l0 = reinterpret_cast<const float*>(lds_px + (size_t)idx * PB);
+            const float* l1 = l0 + (size_t)npx * C;
+#pragma unroll
+            for (int k = 0; k < (INTERP == kLinear ? 2 * C : C); k++) {
+                t0[j][k] = l0[k];
+                if (INTERP == kLinear) t1[j][k] = l1[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if (INTERP == kLinear) {
+                float w00, w01, w10, w11;
+                weights_f32((int)(rawX[j] & 31u), (int)(rawY[j] & 31u), w00, w01, w10, w11);
+#pragma unroll
+                for (int k = 0; k < C; k++) v[j].v[k] = blend_f32(t0[j][k], t0[j][k + C], t1[j][k], t1[j][k + C], w00, w01, w10, w11);
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k++) v[j].v[k] = t0[j][k];
+            }
+        }
+    }
+    // full-lane vector store (the caller checked alignment and that the lane's pixels are inside the row)
+    if constexpr (sizeof(T) == 1 && C == 3) {
+        U3 o;
+        o.x = v[0].packed | (v[1].packed << 24);
+        o.y = (v[1].packed >> 8) | (v[2].packed << 16);
+        o.z = (v[2].packed >> 16) | (v[3].packed << 8);
+        *reinterpret_cast<U3*>(dptr) = o;
+    } else if constexpr (sizeof(T) == 1) {
+        *reinterpret_cast<uint4*>(dptr) = make_uint4(v[0].packed, v[1].packed, v[2].packed, v[3].packed);
+    } else {
+        float f[PPL * C];
+#pragma unroll
+        for (int j = 0; j < PPL; j++)
+#pragma unroll
+            for (int k = 0; k < C; k++) f[j * C + k] = v[j].v[k];
+        if constexpr ((PPL * C) % 4 == 0) {
+#pragma unroll
+            for (int k = 0; k < PPL * C / 4; k++) reinterpret_cast<float4*>(dptr)[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPL * C / 2; k++) reinterpret_cast<float2*>(dptr)[k] = make_float2(f[2 * k], f[2 * k + 1]);
+        }
+    }
+}
+
+// Source region of a band of tile rows, shared through LDS.
+struct Region {
+    int rx0, rx1, ry0, ry1;  // inclusive, clipped to the image; rx1 < rx0 = empty
+    int ax0, npx, rows;      // staged extent (x aligned to 4 pixels)
+    bool ok;                 // corner box is trustworthy (W keeps its sign)
+    bool interior;           // not clipped by the image: every tap of every pixel lies inside
+};
+
+// Diagnostic build only (-DBEVWARP_TIMING): wave 0 of every workgroup adds the shader-clock ticks it spent
+// in each phase to g_phase[]; never compiled into the shipped library (tools/phases.py reads it).
+#ifdef BEVWARP_TIMING
+__device__ unsigned long long g_phase[16];
+#define STAMP(i)                                                                      \
+    do {                                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+        if (threadIdx.x == 0) atomicAdd(&g_phase[i], now_ - stamp_);                  \
+        stamp_ = now_;                                                                \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+#ifndef BEVWARP_WAVES_PER_EU
+#define BEVWARP_WAVES_PER_EU 4
+#endif
 template <typename T, int C, int INTERP>
-__global__ __launch_bounds__(kWG) void warp_tiles(const WarpArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(BEVWARP_WAVES_PER_EU, 8))) void warp_tiles(const WarpArgs a) {
+    constexpr int PPL = pixels_per_lane<T>();
+    constexpr int TW = kLX * PPL;
+    constexpr bool kStagedFmt = has_staged_path<T, C>();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int s_corner[4][3];  // X, Y (fixed point) and sign of W per corner
+    __shared__ int s_corner[4][4];  // X, Y (whole pixels) and sign of W per corner
+
+    double* rowtab = reinterpret_cast<double*>(smem);
+    uint8_t* lds_px = smem + kRowTabBytes;
 
     // ---- which tile: XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs, so ids
     // b and b + 8 share an L2; give each XCD one contiguous run of (frame, tile) items in raster order.
-    const int64_t item = (int64_t)(blockIdx.x & 7) * a.chunk + (blockIdx.x >> 3);
-    if (item >= a.total_tiles) return;
-    const int frame_idx = (int)(item / a.tiles_per_frame);
-    const int t = (int)(item - (int64_t)frame_idx * a.tiles_per_frame);
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const int x0 = tx * kTileW, y0 = ty * a.tile_h;
+    const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
+    if (item >= (uint32_t)a.total_tiles) return;
+    const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
+    const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;
+    const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;
+    const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h;
     const int tid = threadIdx.x;
 
     const uint8_t* __restrict__ frame = a.src + (int64_t)frame_idx * a.src_fs;
@@ -298,100 +538,225 @@ __global__ __launch_bounds__(kWG) void warp_tiles(const WarpArgs a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) Mr[i] = M[i];
 
-    const int x_last = min(x0 + kTileW, a.dst_w) - 1, y_last = min(y0 + a.tile_h, a.dst_h) - 1;
+    const int x_last = min(x0 + TW, a.dst_w) - 1, y_tile_last = min(y0 + a.tile_h, a.dst_h) - 1;
+#ifdef BEVWARP_TIMING
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) atomicAdd(&g_phase[15], 1ull);
+#endif
 
-    // ---- source region of the tile from its four corner pixels
-    constexpr bool kStagedFmt = has_staged_path<T, C>();
-    bool staged = false;
-    int ax0 = 0, ry0 = 0, rows = 0, npx = 0, rx0 = 0, rx1 = -1, ry1 = -1;
-    if (kStagedFmt && a.src_vec_ok) {
-        if (tid < 4) {
-            const int cx = (tid & 1) ? x_last : x0, cy = (tid & 2) ? y_last : y0;
-            const int bx = (cx / a.bw0) * a.bw0;
-            double X0, Y0, W0, W;
-            int X, Y;
-            row_terms(Mr, bx, cy, X0, Y0, W0);
-            const double x1 = (double)(cx - bx);
-            map_pixel<INTERP>(X0, Y0, W0, Mr[0] * x1, Mr[3] * x1, Mr[6] * x1, X, Y, &W);
-            s_corner[tid][0] = INTERP == kLinear ? (X >> kInterBits) : X;
-            s_corner[tid][1] = INTERP == kLinear ? (Y >> kInterBits) : Y;
-            // |W| must stay clear of 0 on the whole tile for the corner box to bound it
-            s_corner[tid][2] = (W > 1e-300) ? 1 : ((W < -1e-300) ? -1 : 0);
-        }
-        __syncthreads();
-        const int sg = s_corner[0][2] + s_corner[1][2] + s_corner[2][2] + s_corner[3][2];
-        const int mnx = min(min(s_corner[0][0], s_corner[1][0]), min(s_corner[2][0], s_corner[3][0]));
-        const int mxx = max(max(s_corner[0][0], s_corner[1][0]), max(s_corner[2][0], s_corner[3][0]));
-        const int mny = min(min(s_corner[0][1], s_corner[1][1]), min(s_corner[2][1], s_corner[3][1]));
-        const int mxy = max(max(s_corner[0][1], s_corner[1][1]), max(s_corner[2][1], s_corner[3][1]));
-        if (sg == 4 || sg == -4) {
-            // +-1 px for rounding inside the tile, +1 for the right / lower tap; clipped to the image.
-            // (64-bit so that saturated coordinates cannot wrap.)
-            const int64_t lx = (int64_t)mnx - 1, hx = (int64_t)mxx + 2, ly = (int64_t)mny - 1, hy = (int64_t)mxy + 2;
-            rx0 = (int)max<int64_t>(lx, 0);
-            rx1 = (int)min<int64_t>(hx, a.src_w - 1);
-            ry0 = (int)max<int64_t>(ly, 0);
-            ry1 = (int)min<int64_t>(hy, a.src_h - 1);
-            if (rx0 <= rx1 && ry0 <= ry1) {
-                ax0 = rx0 & ~3;
-                npx = (rx1 | 3) - ax0 + 1;
-                rows = ry1 - ry0 + 1;
-                staged = (int64_t)rows * npx * lds_pixel_bytes<T, C>() <= (int64_t)a.lds_bytes;
-            }
-        }
-    }
-    if (staged) {
-        if constexpr (kStagedFmt) stage_region<T, C>(a, frame, smem, ax0, ry0, rows, npx, tid);
-        __syncthreads();
-    }
-
-    // ---- per-lane constants
+    // ---- per-lane constants: the lane's PPL pixels sit at x1 = x - bx inside their evaluation block
     const int lane = tid & 63, wave = tid >> 6;
     const int lxi = lane & (kLX - 1), lyi = lane >> 4;
-    const int xg = x0 + lxi * kPPL;  // first pixel of this lane's group
-    int bxj[kPPL];
-    double mx[kPPL], my[kPPL], mw[kPPL];
+    const int xg = x0 + lxi * PPL;
+    const int tile_bx = (int)(fast_div((uint32_t)x0, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+    // every pixel of the tile shares one evaluation block (always true for dst_h >= 16: bw0 = 64 or dst_w)
+    const bool one_bx = (int)(fast_div((uint32_t)(x0 + TW - 1), a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0) == tile_bx;
+    int bxj[PPL];
+    double mx[PPL], my[PPL], mw[PPL];
 #pragma unroll
-    for (int j = 0; j < kPPL; j++) {
+    for (int j = 0; j < PPL; j++) {
         const int x = xg + j;
-        bxj[j] = (x / a.bw0) * a.bw0;
+        bxj[j] = one_bx ? tile_bx : (int)(fast_div((uint32_t)x, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
         const double x1 = (double)(x - bxj[j]);
         mx[j] = Mr[0] * x1;
         my[j] = Mr[3] * x1;
         mw[j] = Mr[6] * x1;
     }
-    const bool one_block = bxj[0] == bxj[kPPL - 1];
-    const int nvalid_x = max(0, min(kPPL, a.dst_w - xg));
-    const uint32_t fast_w = (uint32_t)max(rx1 - rx0 + (INTERP == kLinear ? 0 : 1), 0);  // sx - rx0 < fast_w  <=> sx(+1) in region
-    const uint32_t fast_h = (uint32_t)max(ry1 - ry0 + (INTERP == kLinear ? 0 : 1), 0);
-
-    for (int pass = 0; pass * kRowsPerPass < a.tile_h; pass++) {
-        const int y = y0 + pass * kRowsPerPass + wave * kLY + lyi;
-        if (y > y_last || nvalid_x == 0) continue;
-        double X0, Y0, W0;
-        row_terms(Mr, bxj[0], y, X0, Y0, W0);
-        Pixel<T, C> v[kPPL];
+    const int nvalid_x = max(0, min(PPL, a.dst_w - xg));
+    SrcView view;
+    view.frame = frame;
+    view.rs = a.src_rs;
+    view.w = a.src_w;
+    view.h = a.src_h;
 #pragma unroll
-        for (int j = 0; j < kPPL; j++) {
-            if (!one_block && j > 0) row_terms(Mr, bxj[j], y, X0, Y0, W0);
-            int X, Y;
-            map_pixel<INTERP>(X0, Y0, W0, mx[j], my[j], mw[j], X, Y);
-            const int sx = INTERP == kLinear ? (X >> kInterBits) : X, sy = INTERP == kLinear ? (Y >> kInterBits) : Y;
-            const uint32_t ox = (uint32_t)(sx - rx0), oy = (uint32_t)(sy - ry0);
-            bool fast = false;
-            if constexpr (kStagedFmt) fast = staged && ox < fast_w && oy < fast_h;
-            if (fast) {
-                const uint32_t px = (uint32_t)(sy - ry0) * (uint32_t)npx + (uint32_t)(sx - ax0);
-                if constexpr (kStagedFmt) v[j] = sample_lds<T, C, INTERP>(smem, px, (uint32_t)npx, X & 31, Y & 31);
-            } else {
-                v[j] = sample_global<T, C, INTERP>(a, frame, X, Y);
+    for (int k = 0; k < 4; k++) view.bf[k] = a.bval_f[k];
+    view.bu = (uint32_t)a.bval_u8[0] | ((uint32_t)a.bval_u8[1] << 8) | ((uint32_t)a.bval_u8[2] << 16) | ((uint32_t)a.bval_u8[3] << 24);
+
+    STAMP(0);  // matrix load + per-lane constants
+    // ---- bands: the whole tile if its source region fits the LDS budget, else 16 rows at a time
+    const bool can_stage = kStagedFmt && a.src_vec_ok;
+    int band_h = a.tile_h;
+    bool first = true;
+    for (int y_lo = y0; y_lo <= y_tile_last;) {
+        const int y_hi = min(y_lo + band_h, y_tile_last + 1) - 1;
+        // -- corners of the band (approximate chain is enough: the box gets a 2-pixel margin) and row table
+        if (!first) __syncthreads();  // the previous band's LDS reads are done
+        first = false;
+        if (can_stage && tid < 4) {
+            const int cx = (tid & 1) ? x_last : x0, cy = (tid & 2) ? y_hi : y_lo;
+            const int bx = (int)(fast_div((uint32_t)cx, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+            double X0, Y0, W0;
+            row_terms(Mr, bx, cy, X0, Y0, W0);
+            const double x1 = (double)(cx - bx);
+            const double W = W0 + Mr[6] * x1;
+            const double r = rcp_newton(W);
+            const double px = (X0 + Mr[0] * x1) * r, py = (Y0 + Mr[3] * x1) * r;
+            // whole-pixel coordinate, saturated well inside int range; NaN -> flagged through sign 0
+            const bool fin = fabs(px) < 1e9 && fabs(py) < 1e9;
+            s_corner[tid][0] = fin ? (int)floor(px) : 0;
+            s_corner[tid][1] = fin ? (int)floor(py) : 0;
+            // W must keep its sign and a sane magnitude on the band (it is linear, so the corners bound it):
+            // the shared reciprocal multiplies up to four of them.
+            s_corner[tid][2] = (!fin || !(fabs(W) > 1e-60 && fabs(W) < 1e60)) ? 0 : (W > 0 ? 1 : -1);
+        }
+        if (one_bx && tid >= 64 && tid < 64 + (y_hi - y_lo + 1)) {
+            double X0, Y0, W0;
+            row_terms(Mr, tile_bx, y_lo + tid - 64, X0, Y0, W0);
+            rowtab[(tid - 64) * 3 + 0] = X0;
+            rowtab[(tid - 64) * 3 + 1] = Y0;
+            rowtab[(tid - 64) * 3 + 2] = W0;
+        }
+        __syncthreads();
+        STAMP(1);  // corners + row table + barrier
+
+        Region R;
+        R.rx0 = 0, R.rx1 = -1, R.ry0 = 0, R.ry1 = -1, R.ax0 = 0, R.npx = 0, R.rows = 0, R.ok = false, R.interior = false;
+        bool staged = false;
+        if (can_stage) {
+            int c[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) c[i][k] = __builtin_amdgcn_readfirstlane(s_corner[i][k]);
+            const int sg = c[0][2] + c[1][2] + c[2][2] + c[3][2];
+            if (sg == 4 || sg == -4) {
+                // +-2 px: rounding inside the band and the approximate corner chain; +1: right / lower tap
+                const int lx = min(min(c[0][0], c[1][0]), min(c[2][0], c[3][0])) - 2;
+                const int hx = max(max(c[0][0], c[1][0]), max(c[2][0], c[3][0])) + 3;
+                const int ly = min(min(c[0][1], c[1][1]), min(c[2][1], c[3][1])) - 2;
+                const int hy = max(max(c[0][1], c[1][1]), max(c[2][1], c[3][1])) + 3;
+                R.ok = true;
+                R.rx0 = max(lx, 0);
+                R.rx1 = min(hx, a.src_w - 1);
+                R.ry0 = max(ly, 0);
+                R.ry1 = min(hy, a.src_h - 1);
+                R.interior = lx >= 0 && hx <= a.src_w - 1 && ly >= 0 && hy <= a.src_h - 1;
+                if (R.rx0 <= R.rx1 && R.ry0 <= R.ry1) {
+                    R.ax0 = R.rx0 & ~3;
+                    R.npx = (R.rx1 | 3) - R.ax0 + 1;
+                    R.rows = R.ry1 - R.ry0 + 1;
+                    staged = (int64_t)R.rows * R.npx * lds_pixel_bytes<T, C>() <= (int64_t)a.lds_bytes;
+                }
+            }
+            const bool outside = R.ok && (R.rx0 > R.rx1 || R.ry0 > R.ry1);  // nothing of the band samples the image
+            if (!staged && !outside && band_h > kBandRows) {
+                band_h = kBandRows;  // box too big for LDS (or not trustworthy): retry this tile in 16-row bands
+                continue;
             }
         }
-        store_pixels<T, C>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
+        STAMP(2);  // region
+        if (staged) {
+            if constexpr (kStagedFmt) stage_region<T, C>(a, frame, lds_px, R.ax0, R.ry0, R.rows, R.npx, tid);
+            STAMP(3);  // staging loads + LDS writes of this wave
+            __syncthreads();
+            STAMP(4);  // staging barrier
+        }
+        const bool interior = staged && R.interior;
+        const uint32_t fast_w = (uint32_t)max(R.rx1 - R.rx0 + (INTERP == kLinear ? 0 : 1), 0);  // sx - rx0 < fast_w <=> taps inside
+        const uint32_t fast_h = (uint32_t)max(R.ry1 - R.ry0 + (INTERP == kLinear ? 0 : 1), 0);
+        const int px_bias = -R.ry0 * R.npx - R.ax0;  // LDS pixel index = sy * npx + sx + px_bias
+
+        // -- fast rows: every tap of the band lies inside the staged region, full lanes, one evaluation block
+        if constexpr (kStagedFmt) {
+            if (interior && one_bx && x0 + TW <= a.dst_w && a.dst_vec_ok) {
+                constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);  // raw coordinates carry + 2^31
+                const uint32_t idx_bias = (uint32_t)px_bias - kRawBias * (uint32_t)R.npx - kRawBias;
+                for (int y = y_lo + wave * kLY + lyi; y <= y_hi; y += kBandRows)
+                    row_fast<T, C, INTERP, PPL>(rowtab + (y - y_lo) * 3, mx, my, mw, lds_px, (uint32_t)R.npx, idx_bias,
+                                                dframe + (int64_t)y * a.dst_rs + (int64_t)xg * C * sizeof(T));
+                y_lo = y_hi + 1;
+                STAMP(5);  // fast rows
+                continue;
+            }
+        }
+        // -- general rows (image border, ragged tiles, unstaged bands)
+        const bool approx_ok = R.ok;  // the shared-reciprocal shortcut needs W of one sign and sane magnitude
+        for (int y = y_lo + wave * kLY + lyi; y <= y_hi; y += kBandRows) {
+            if (nvalid_x == 0) break;
+            double X0, Y0, W0;
+            if (one_bx) {
+                X0 = rowtab[(y - y_lo) * 3 + 0];
+                Y0 = rowtab[(y - y_lo) * 3 + 1];
+                W0 = rowtab[(y - y_lo) * 3 + 2];
+            } else {
+                row_terms(Mr, bxj[0], y, X0, Y0, W0);
+            }
+            double Wj[PPL], Xn[PPL], Yn[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                if (!one_bx && j > 0 && bxj[j] != bxj[j - 1]) row_terms(Mr, bxj[j], y, X0, Y0, W0);
+                Wj[j] = W0 + mw[j];
+                Xn[j] = X0 + mx[j];
+                Yn[j] = Y0 + my[j];
+            }
+            // one reciprocal for the lane's pixels: 1 / (W0 W1 [W2 W3]) and back-substitution
+            double rj[PPL];
+            if constexpr (PPL == 4) {
+                const double p01 = Wj[0] * Wj[1], p23 = Wj[2] * Wj[3];
+                const double inv = rcp_newton(p01 * p23);
+                const double i01 = inv * p23, i23 = inv * p01;
+                rj[0] = i01 * Wj[1];
+                rj[1] = i01 * Wj[0];
+                rj[2] = i23 * Wj[3];
+                rj[3] = i23 * Wj[2];
+            } else {
+                const double inv = rcp_newton(Wj[0] * Wj[1]);
+                rj[0] = inv * Wj[1];
+                rj[1] = inv * Wj[0];
+            }
+            int X[PPL], Y[PPL];
+            uint32_t redo = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool okx = round_fast<INTERP>(Xn[j] * rj[j], X[j]);
+                const bool oky = round_fast<INTERP>(Yn[j] * rj[j], Y[j]);
+                if (!(approx_ok && okx && oky)) redo |= 1u << j;
+            }
+            if (redo) {  // rare: rounding ties, W == 0, non-finite or far-away coordinates -> the exact chain decides
+#pragma unroll
+                for (int j = 0; j < PPL; j++)
+                    if (redo & (1u << j)) map_pixel_exact<INTERP>(Xn[j], Yn[j], Wj[j], X[j], Y[j]);
+            }
+            Pixel<T, C> v[PPL];
+            uint32_t slow = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const int sx = INTERP == kLinear ? (X[j] >> kInterBits) : X[j], sy = INTERP == kLinear ? (Y[j] >> kInterBits) : Y[j];
+                bool fast = interior;
+                if (!interior) fast = staged && (uint32_t)(sx - R.rx0) < fast_w && (uint32_t)(sy - R.ry0) < fast_h;
+                if (fast) {
+                    if constexpr (kStagedFmt)
+                        v[j] = sample_lds<T, C, INTERP>(lds_px, (uint32_t)(sy * R.npx + sx + px_bias), (uint32_t)R.npx, X[j] & 31, Y[j] & 31);
+                } else {
+                    slow |= 1u << j;
+                }
+            }
+            if (slow) {  // image border, unstaged bands
+#pragma unroll
+                for (int j = 0; j < PPL; j++)
+                    if (slow & (1u << j)) v[j] = sample_global<T, C, INTERP>(view, X[j], Y[j]);
+            }
+            store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
+        }
+        y_lo = y_hi + 1;
+        STAMP(6);  // general rows
     }
 }
 
-// Footprint: mark every in-bounds source pixel any tap would read (measurement aid).
+#ifdef BEVWARP_TIMING
+}  // namespace
+hipError_t debug_read_phases(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    }
+    return e;
+}
+namespace {
+#endif
+
+// Footprint: mark every in-bounds source pixel any tap would read (measurement aid; exact chain).
 template <int INTERP>
 __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch, int src_h, int src_w, int dst_h, int dst_w,
                                  const double* __restrict__ minv, int m_stride, int bw0) {
@@ -406,7 +771,7 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
     row_terms(Mr, bx, y, X0, Y0, W0);
     const double x1 = (double)(x - bx);
     int X, Y;
-    map_pixel<INTERP>(X0, Y0, W0, Mr[0] * x1, Mr[3] * x1, Mr[6] * x1, X, Y);
+    map_pixel_exact<INTERP>(X0 + Mr[0] * x1, Y0 + Mr[3] * x1, W0 + Mr[6] * x1, X, Y);
     const int sx = INTERP == kLinear ? (X >> kInterBits) : X, sy = INTERP == kLinear ? (Y >> kInterBits) : Y;
     unsigned char* tb = touched + (int64_t)b * src_h * src_w;
     const int ntap = INTERP == kLinear ? 2 : 1;
@@ -438,12 +803,12 @@ hipError_t launch_t(const WarpArgs& a, int channels, int interp, dim3 grid, size
 
 }  // namespace
 
-int tile_width() { return kTileW; }
-int rows_per_pass() { return kRowsPerPass; }
+int tile_width(int dtype) { return dtype == 0 ? kLX * pixels_per_lane<uint8_t>() : kLX * pixels_per_lane<float>(); }
+int band_rows() { return kBandRows; }
 
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream) {
     const dim3 grid((unsigned)(8 * a.chunk));
-    const size_t lds = (size_t)a.lds_bytes;
+    const size_t lds = (size_t)a.lds_bytes + kRowTabBytes;
     return dtype == 0 ? launch_t<uint8_t>(a, channels, interp, grid, lds, stream) : launch_t<float>(a, channels, interp, grid, lds, stream);
 }
 
