@@ -1,0 +1,113 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/bevwarp.h declares,
+validates arguments before touching the device, and its host helper matches the oracle.  No GPU work."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bev_amd import _lib
+from oracle import cpu_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "bevwarp.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(bevwarp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 8 and "bevwarp_warp" in names
+    assert sorted(_lib.SYMBOLS) == names  # the ctypes table and the header agree
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert getattr(raw, n) is not None
+    assert lib.bevwarp_version() == _lib.ABI_VERSION == 1
+
+
+def test_header_cites_the_reference_interfaces():
+    with open(os.path.join(ROOT, "include", "bevwarp.h")) as f:
+        text = f.read()
+    for cite in ("vis_homo.py:89", "bev/tool/compo.py:38", "bev/rbox.py:136-151", "bev/tracker/rbox_tracker.py:87-92"):
+        assert cite in text
+
+
+def test_strerror_and_argument_validation_without_a_device(lib):
+    assert lib.bevwarp_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert len(lib.bevwarp_strerror(code)) > 4
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    warp = lib.bevwarp_warp
+    ok_args = [one, one, 1, 8, 8, 8, 8, 3, 192, 24, 192, 24, one, 1, _lib.U8, 1, None, None]
+
+    def call(**patch):
+        a = list(ok_args)
+        for k, v in patch.items():
+            a[int(k[1:])] = v
+        return warp(*a)
+
+    assert call(a0=None) == -1          # null src
+    assert call(a2=-1) == -1            # negative batch
+    assert call(a7=5) == -2             # 5 channels
+    assert call(a14=7) == -2            # unknown dtype
+    assert call(a15=3) == -2            # unknown interpolation
+    assert call(a9=23) == -1            # row stride shorter than a row
+    assert call(a13=2) == -1            # 2 matrices for a batch of 1
+    assert call(a4=40000, a9=120000, a8=960000) == -3  # source wider than 32767
+    assert call(a2=0) == 0              # empty batch is a no-op
+    bad_border = (ctypes.c_double * 3)(0.0, float("nan"), 0.0)
+    assert call(a16=ctypes.cast(bad_border, ctypes.c_void_p)) == -4
+    H = (ctypes.c_double * 9)(*[float("inf")] * 9)
+    assert lib.bevwarp_project_points(one, one, 4, 2, ctypes.cast(H, ctypes.c_void_p), _lib.F64, None) == -4
+    assert lib.bevwarp_project_points(one, one, 4, 5, ctypes.cast(H, ctypes.c_void_p), _lib.F64, None) == -1
+    assert lib.bevwarp_rbox_iou(one, 4, 3, one, 4, 5, one, _lib.F64, None) == -1
+    assert lib.bevwarp_footprint(None, 1, 8, 8, 8, 8, one, 1, 1, None) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1)
+
+
+def test_host_inverse_matches_oracle_bit_for_bit():
+    from bev_amd.warp import invert_homography
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(64, 3, 3)) * rng.choice([1e-3, 1.0, 1e3], size=(64, 1, 1))
+    got = invert_homography(M)
+    for i in range(64):
+        np.testing.assert_array_equal(got[i], co.invert3x3(M[i]))
+    assert not invert_homography(np.ones((3, 3))).any()  # singular -> zeros, like cv::invert
+    with pytest.raises(ValueError):
+        invert_homography(np.full((3, 3), np.nan))
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from bev_amd import iou, points, warp
+    with pytest.raises(ValueError):
+        warp.warp_perspective(torch.zeros((8, 8, 3), dtype=torch.uint8), np.eye(3), (8, 8))
+    with pytest.raises(ValueError):
+        points.project_points(torch.zeros((4, 2)), np.eye(3))
+    with pytest.raises(ValueError):
+        iou.rbox_iou(torch.zeros((1, 5)), torch.zeros((1, 5)))
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under bev_amd/ or bev/ may reference it."""
+    for pkg in ("bev_amd", "bev"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                    with open(os.path.join(dirpath, fn)) as f:
+                        src = f.read()
+                    assert "cpu_oracle" not in src and "liboracle" not in src and "from oracle" not in src, os.path.join(dirpath, fn)
