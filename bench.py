@@ -54,7 +54,11 @@ def parse():
 def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
     """Time the oracle (kind "port") on a bounded sample; also use it as the checker of the GPU output."""
     from oracle import cpu_oracle as co
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # a one-GPU box owns a 16-core share of the host
     dw, dh = dsize
     mpix = dw * dh / 1e6
     # all cores (OpenMP over 16-row stripes)

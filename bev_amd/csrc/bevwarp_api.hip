@@ -127,9 +127,20 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     a.bw0 = block_width(dst_w, dst_h);
     // tile = tile_width x tile_h destination pixels per workgroup; the source box of a tile must fit
     // lds_bytes or the tile is redone in 16-row bands (tunable for experiments through the environment)
-    a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 32 : 16);
-    if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows()) a.tile_h = 16;
     const int tw = tile_width(dtype);
+    // two kernels: warp_tiles stages source tiles in LDS; warp_gather samples global memory directly and needs
+    // every tile inside one evaluation block.  BEVWARP_MODE: 0 = pick (default), 1 = staged, 2 = gather.
+    const int mode = env_int("BEVWARP_MODE", 0);
+    const bool gather_ok = (a.bw0 % tw == 0) || (a.bw0 >= dst_w);
+    // BEVWARP_MODE 3 = warp_wave (wave-private LDS tiles by LDS-DMA), same eligibility as gather
+    a.gather = !gather_ok ? 0 : (mode == 3 ? 2 : ((mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1))) ? 1 : 0));
+    if (a.gather) {
+        a.tile_h = env_int("BEVWARP_GATHER_TILE_H", 64);
+        if (a.tile_h < 16 || a.tile_h > 1024 || a.tile_h % band_rows()) a.tile_h = 64;
+    } else {
+        a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 32 : 16);
+        if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows()) a.tile_h = 16;
+    }
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
     a.tiles_per_frame = a.tiles_x * tiles_y;
@@ -144,16 +155,22 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     a.tpf_magic = magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
     a.tx_magic = magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
     a.bw0_magic = magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
-    a.lds_bytes = env_int("BEVWARP_LDS_BYTES", 32 * 1024);
-    if (a.lds_bytes < 0) a.lds_bytes = 0;
-    if (a.lds_bytes > 60 * 1024) a.lds_bytes = 60 * 1024;
+    if (a.gather == 2) {  // per-wave slot
+        a.lds_bytes = env_int("BEVWARP_SLOT_BYTES", dtype == BEVWARP_U8 ? 8 * 1024 : 12 * 1024);
+        if (a.lds_bytes < 1024) a.lds_bytes = 1024;
+        if (a.lds_bytes > 15 * 1024) a.lds_bytes = 15 * 1024;
+    } else {
+        a.lds_bytes = env_int("BEVWARP_LDS_BYTES", 32 * 1024);
+        if (a.lds_bytes < 0) a.lds_bytes = 0;
+        if (a.lds_bytes > 60 * 1024) a.lds_bytes = 60 * 1024;
+    }
     a.lds_bytes &= ~15;
 
     // staged loads: u8x3 reads 12-byte groups (4-byte aligned), the other formats 16-byte chunks;
     // both need the row to end on a 4-pixel boundary so a group never crosses into the next row.
     const bool u8x3 = dtype == BEVWARP_U8 && channels == 3;
-    const int src_align = u8x3 ? 4 : 16;
-    a.src_vec_ok = (src_w % 4 == 0) && ((uintptr_t)src % src_align == 0) && (src_row_stride % src_align == 0) &&
+    const int src_align = (u8x3 && a.gather != 2) ? 4 : 16;
+    a.src_vec_ok = (src_w % 4 == 0 || a.gather == 2) && ((uintptr_t)src % src_align == 0) && (src_row_stride % src_align == 0) &&
                    (src_frame_stride % src_align == 0) && a.lds_bytes > 0 && !env_int("BEVWARP_NO_LDS", 0);
     const int dst_align = u8x3 ? 4 : 16;
     a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);

@@ -26,6 +26,7 @@ struct WarpArgs {
     int lds_bytes;               // dynamic LDS given to the staged region
     int src_vec_ok;              // source layout admits the aligned staging loads
     int dst_vec_ok;              // destination layout admits the wide stores
+    int gather;                  // 1 = warp_gather (no LDS staging), 0 = warp_tiles
     float bval_f[4];
     uint8_t bval_u8[4];
 };

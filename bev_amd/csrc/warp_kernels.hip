@@ -146,13 +146,13 @@ __device__ __forceinline__ uint32_t blend_u8_packed(uint32_t p00, uint32_t p01, 
     const uint32_t t01 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
     const uint32_t b01 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
     uint32_t s[4];
-    s[0] = __builtin_amdgcn_udot4(t01, wlo, 0u, false) * wy0 + __builtin_amdgcn_udot4(b01, wlo, 0u, false) * wy1 + 32768u;
-    if (C > 1) s[1] = __builtin_amdgcn_udot4(t01, whi, 0u, false) * wy0 + __builtin_amdgcn_udot4(b01, whi, 0u, false) * wy1 + 32768u;
+    s[0] = __umul24(__builtin_amdgcn_udot4(t01, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b01, wlo, 0u, false), wy1) + 32768u);
+    if (C > 1) s[1] = __umul24(__builtin_amdgcn_udot4(t01, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b01, whi, 0u, false), wy1) + 32768u);
     if (C > 2) {
         const uint32_t t23 = __builtin_amdgcn_perm(p01, p00, 0x07030602u);
         const uint32_t b23 = __builtin_amdgcn_perm(p11, p10, 0x07030602u);
-        s[2] = __builtin_amdgcn_udot4(t23, wlo, 0u, false) * wy0 + __builtin_amdgcn_udot4(b23, wlo, 0u, false) * wy1 + 32768u;
-        if (C > 3) s[3] = __builtin_amdgcn_udot4(t23, whi, 0u, false) * wy0 + __builtin_amdgcn_udot4(b23, whi, 0u, false) * wy1 + 32768u;
+        s[2] = __umul24(__builtin_amdgcn_udot4(t23, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b23, wlo, 0u, false), wy1) + 32768u);
+        if (C > 3) s[3] = __umul24(__builtin_amdgcn_udot4(t23, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b23, whi, 0u, false), wy1) + 32768u);
     }
     // gather byte 2 of every sum
     uint32_t out = (C > 1) ? __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u) : ((s[0] >> 16) & 0xffu);
@@ -279,13 +279,37 @@ __device__ __forceinline__ void stage_region(const WarpArgs& a, const uint8_t* _
     const int q0 = tid & (lanes - 1);
     const uint8_t* base = frame + (int64_t)ry0 * a.src_rs + (int64_t)ax0 * (kWiden ? 3 : PB);
     uint4* l = reinterpret_cast<uint4*>(lds);
+    if constexpr (!kWiden) {
+        // Natural layout: LDS-DMA (global_load_lds_dwordx4).  No VGPR staging and no ds_write: a wave-instruction
+        // moves 64 consecutive 16-byte chunks (its lanes' global addresses are free) to 1 KiB of LDS at a
+        // wave-uniform base, so the dense row-major image is filled in chunk order and every load of the
+        // region is in flight at once.
+        const int total = rows * upr;
+        int r = tid / upr, q = tid - r * upr;  // chunk -> (row, column) once; then steps of 256 chunks
+        const int dr = kWG / upr, dq = kWG - dr * upr;
+        for (int c0 = 0; c0 < total; c0 += kWG) {
+            if (c0 + tid < total) {
+                const uint8_t* g = base + (int64_t)r * a.src_rs + q * 16;
+                uint8_t* lw = lds + (size_t)(c0 + (tid & ~63)) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)lw, 16, 0, 0);
+            }
+            q += dq;
+            r += dr;
+            if (q >= upr) {
+                q -= upr;
+                r++;
+            }
+        }
+        return;
+    }
     using Unit = typename std::conditional<kWiden, U3, uint4>::type;
     constexpr int UB = kWiden ? 12 : 16;
     // Memory-level parallelism: a thread first ISSUES up to kBatch loads (its rows of kBatch consecutive
     // passes), then widens / writes them to LDS -- one exposed HBM latency per batch instead of per load.
     // Branch-free inside a batch (rows past the end are clamped to the last row: a redundant, identical
     // load + store) so that the compiler emits the loads back to back instead of load / wait / write chains.
-    constexpr int kBatch = 4;
+    constexpr int kBatch = 8;
     const int last = rows - 1;
     for (int q = q0; q < upr; q += lanes) {
         for (int r0 = tid >> lg; r0 < rows; r0 += rstep * kBatch) {
@@ -756,6 +780,437 @@ hipError_t debug_read_phases(unsigned long long* out16, int reset) {
 namespace {
 #endif
 
+// ===================================================================================================
+// warp_gather: the same warp WITHOUT LDS staging.  Every lane loads its taps straight from global
+// memory (two unaligned 8-byte loads per 8-bit RGB pixel: the 6 bytes of a tap pair + 2 spare) and
+// relies on the vector L1 / per-XCD L2 for the reuse between neighbouring pixels.  No barriers, no
+// LDS: occupancy is bounded by registers only and a wave keeps all the loads of its PPL pixels in
+// flight.  Requires every TW-wide tile to lie in one evaluation block (host checks).
+// ===================================================================================================
+template <int N>
+struct Bytes {
+    uint32_t w[N / 4];
+};
+
+template <typename T, int C, int INTERP>
+__global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
+    constexpr int PPL = pixels_per_lane<T>();
+    constexpr int TW = kLX * PPL;
+    constexpr int PBs = (int)sizeof(T) * C;                      // source bytes per pixel
+    constexpr int TAPB = INTERP == kLinear ? 2 * PBs : PBs;      // bytes of one row's taps
+    constexpr int LOADB = (TAPB + 3) & ~3;                       // loaded per row (whole dwords)
+    constexpr double kScale = INTERP == kLinear ? 33554432.0 : 1048576.0;
+    constexpr double kMagic = 6755399441055744.0 + 524288.0;
+    constexpr int SH = INTERP == kLinear ? kInterBits : 0;
+
+    const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
+    if (item >= (uint32_t)a.total_tiles) return;
+    const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
+    const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;
+    const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;
+    const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h;
+    const int tid = threadIdx.x;
+    const uint8_t* __restrict__ frame = a.src + (int64_t)frame_idx * a.src_fs;
+    uint8_t* __restrict__ dframe = a.dst + (int64_t)frame_idx * a.dst_fs;
+    const double* __restrict__ M = a.minv + (int64_t)frame_idx * a.m_stride;
+    double Mr[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Mr[i] = M[i];
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lxi = lane & (kLX - 1), lyi = lane >> 4;
+    const int xg = x0 + lxi * PPL;
+    const int tile_bx = (int)(fast_div((uint32_t)x0, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+    double mx[PPL], my[PPL], mw[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        const double x1 = (double)(xg + j - tile_bx);
+        mx[j] = Mr[0] * x1;
+        my[j] = Mr[3] * x1;
+        mw[j] = Mr[6] * x1;
+    }
+    // row-independent products of the row terms (X0 = (M0*bx + M1*y) + M2)
+    const double bxd = (double)tile_bx;
+    const double bX = Mr[0] * bxd, bY = Mr[3] * bxd, bW = Mr[6] * bxd;
+    const int nvalid_x = max(0, min(PPL, a.dst_w - xg));
+    const int y_last = min(y0 + a.tile_h, a.dst_h) - 1;
+    SrcView view;
+    view.frame = frame;
+    view.rs = a.src_rs;
+    view.w = a.src_w;
+    view.h = a.src_h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) view.bf[k] = a.bval_f[k];
+    view.bu = (uint32_t)a.bval_u8[0] | ((uint32_t)a.bval_u8[1] << 8) | ((uint32_t)a.bval_u8[2] << 16) | ((uint32_t)a.bval_u8[3] << 24);
+    // an unguarded row load reads LOADB bytes from the tap: it must stay inside the row
+    const int sx_lim = (int)(((int64_t)a.src_w * PBs - LOADB) / PBs);  // largest sx with sx*PBs + LOADB <= w*PBs
+    const int sy_lim = a.src_h - (INTERP == kLinear ? 2 : 1);
+    const bool any_fast = (int64_t)a.src_w * PBs >= LOADB && sy_lim >= 0;
+    const uint32_t sx_max = any_fast ? (uint32_t)sx_lim : 0u, sy_max = any_fast ? (uint32_t)sy_lim : 0u;
+
+    // -- one row of the lane: exact fixed-point coordinates; returns whether unguarded loads are allowed
+    auto coords = [&](int y, int (&X)[PPL], int (&Y)[PPL]) -> bool {
+        const double dy = (double)y;
+        const double X0 = (bX + Mr[1] * dy) + Mr[2], Y0 = (bY + Mr[4] * dy) + Mr[5], W0 = (bW + Mr[7] * dy) + Mr[8];
+        double W[PPL], r[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) W[j] = W0 + mw[j];
+        if constexpr (PPL == 4) {
+            const double p01 = W[0] * W[1], p23 = W[2] * W[3];
+            const double inv = rcp_newton(p01 * p23) * kScale;
+            const double i01 = inv * p23, i23 = inv * p01;
+            r[0] = i01 * W[1];
+            r[1] = i01 * W[0];
+            r[2] = i23 * W[3];
+            r[3] = i23 * W[2];
+        } else {
+            const double inv = rcp_newton(W[0] * W[1]) * kScale;
+            r[0] = inv * W[1];
+            r[1] = inv * W[0];
+        }
+        // W is linear along the row: its end values bound the lane's pixels.  The shared reciprocal needs one
+        // sign and a sane magnitude (no overflow / denormals in the product), else the exact chain runs.
+        const double wa = W[0], wb = W[PPL - 1];
+        const bool w_ok = (wa > 0) == (wb > 0) && fabs(wa) > 1e-60 && fabs(wa) < 1e60 && fabs(wb) > 1e-60 && fabs(wb) < 1e60;
+        uint32_t tie = 0xffffffffu, expo = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+            const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
+            const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
+            X[j] = (int)(__builtin_amdgcn_alignbit(hix, lox, 20) ^ 0x80000000u);
+            Y[j] = (int)(__builtin_amdgcn_alignbit(hiy, loy, 20) ^ 0x80000000u);
+            tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+            // the mantissa trick holds while the sum keeps the magic's exponent (|coordinate| < 2^31)
+            expo |= (hix ^ 0x43300000u) | (hiy ^ 0x43300000u);
+        }
+        if (tie == 0 || (expo >> 20) != 0 || !w_ok) {  // rare: tie window, non-finite / huge coordinates, W near 0
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
+                const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
+                // |coordinate| >= 2^22 (1/32 px units) is far outside any admissible image but no longer exact: redo too
+                const bool far = (uint32_t)(X[j] + (1 << 22)) >= (1u << 23) || (uint32_t)(Y[j] + (1 << 22)) >= (1u << 23);
+                if (!w_ok || far || ((lox + 2u) & 0xffffcu) == 0 || ((loy + 2u) & 0xffffcu) == 0 || ((hix ^ 0x43300000u) >> 20) != 0 ||
+                    ((hiy ^ 0x43300000u) >> 20) != 0)
+                    map_pixel_exact<INTERP>(X0 + mx[j], Y0 + my[j], W[j], X[j], Y[j]);
+            }
+        }
+        // taps fully inside the frame (and the dword-rounded loads inside their row)?
+        bool inb = any_fast && nvalid_x == PPL;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) inb = inb && (uint32_t)(X[j] >> SH) <= sx_max && (uint32_t)(Y[j] >> SH) <= sy_max;
+        return inb;
+    };
+    // -- issue the row's tap loads (32-bit offsets: a frame is < 2 GiB)
+    const uint32_t rs32 = (uint32_t)a.src_rs;
+    auto issue = [&](const int (&X)[PPL], const int (&Y)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const uint32_t off = (uint32_t)(Y[j] >> SH) * rs32 + (uint32_t)(X[j] >> SH) * (uint32_t)PBs;
+            __builtin_memcpy(&t0[j], frame + off, LOADB);
+            if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + off + rs32, LOADB);
+        }
+    };
+    // -- blend (or border-sample) and store the row
+    auto finish = [&](int y, bool fast, const int (&X)[PPL], const int (&Y)[PPL], const Bytes<LOADB> (&t0)[PPL], const Bytes<LOADB> (&t1)[PPL]) {
+        Pixel<T, C> v[PPL];
+        if (__builtin_expect(fast, 1)) {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const uint32_t fx = (uint32_t)X[j] & 31u, fy = (uint32_t)Y[j] & 31u;
+                if constexpr (sizeof(T) == 1) {
+                    if (INTERP == kNearest) {
+                        v[j].packed = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+                    } else {
+                        // left tap = bytes 0..C-1, right tap = bytes C..2C-1 of the row's load
+                        uint32_t l0, r0, l1, r1;
+                        if constexpr (C == 4) {
+                            l0 = t0[j].w[0], r0 = t0[j].w[1], l1 = t1[j].w[0], r1 = t1[j].w[1];
+                        } else if constexpr (C == 3) {
+                            l0 = t0[j].w[0], r0 = __builtin_amdgcn_alignbyte(t0[j].w[1], t0[j].w[0], 3);
+                            l1 = t1[j].w[0], r1 = __builtin_amdgcn_alignbyte(t1[j].w[1], t1[j].w[0], 3);
+                        } else {
+                            l0 = t0[j].w[0], r0 = t0[j].w[0] >> (8 * C), l1 = t1[j].w[0], r1 = t1[j].w[0] >> (8 * C);
+                        }
+                        v[j].packed = blend_u8_packed<C>(l0, r0, l1, r1, fx, fy);  // bytes >= C of the taps are never selected
+                    }
+                } else {
+                    const float* f0 = reinterpret_cast<const float*>(&t0[j]);
+                    const float* f1 = reinterpret_cast<const float*>(&t1[j]);
+                    if (INTERP == kNearest) {
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = f0[k];
+                    } else {
+                        float w00, w01, w10, w11;
+                        weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) v[j] = sample_global<T, C, INTERP>(view, X[j], Y[j]);
+        }
+        store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
+    };
+
+    // -- rows, software-pipelined: the loads of a row are in flight while the next row's coordinates are computed
+    int y = y0 + wave * kLY + lyi;
+    if (y > y_last || nvalid_x == 0) return;
+    int Xc[PPL], Yc[PPL];
+    Bytes<LOADB> t0[PPL], t1[PPL];
+    bool fc = coords(y, Xc, Yc);
+    if (fc) issue(Xc, Yc, t0, t1);
+    for (;;) {
+        const int yn = y + kBandRows;
+        const bool has_next = yn <= y_last;
+        int Xn[PPL], Yn[PPL];
+        bool fn = false;
+        if (has_next) fn = coords(yn, Xn, Yn);
+        finish(y, fc, Xc, Yc, t0, t1);
+        if (!has_next) break;
+        if (fn) issue(Xn, Yn, t0, t1);
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            Xc[j] = Xn[j];
+            Yc[j] = Yn[j];
+        }
+        fc = fn;
+        y = yn;
+    }
+}
+
+// ===================================================================================================
+// warp_wave: wave-private LDS tiles filled by LDS-DMA.  Each WAVE (64 lanes = 16 x 4 block of lanes,
+// PPL pixels per lane) computes its block's exact fixed-point coordinates, takes the source bounding
+// box from its four corner lanes (v_readlane), copies that box from global memory to its own LDS slot
+// with global_load_lds_dwordx4 (coalesced 16-byte chunks, no VGPR staging, no widening) and samples
+// from LDS.  No workgroup barrier anywhere: the only synchronisation is the wave's own vmcnt.
+// Compared with warp_gather the texture-address unit sees a handful of coalesced 1 KiB instructions
+// per block instead of 64-address gathers; compared with warp_tiles there is no barrier, no corner
+// approximation (the box comes from the pixels' real coordinates) and occupancy is not tied to a
+// whole-workgroup tile.  Blocks whose box is clipped by the image, exceeds the slot, or whose layout is
+// not 16-byte aligned fall back to the per-lane gather of the same iteration.
+// ===================================================================================================
+template <typename T, int C, int INTERP>
+__global__ __launch_bounds__(kWG) void warp_wave(const WarpArgs a) {
+    constexpr int PPL = pixels_per_lane<T>();
+    constexpr int TW = kLX * PPL;
+    constexpr int PBs = (int)sizeof(T) * C;
+    constexpr int TAPB = INTERP == kLinear ? 2 * PBs : PBs;
+    constexpr int LOADB = (TAPB + 3) & ~3;
+    constexpr bool kFunnel = (PBs % 4) != 0;  // taps are not dword aligned in LDS: read one more dword and shift
+    constexpr double kScale = INTERP == kLinear ? 33554432.0 : 1048576.0;
+    constexpr double kMagic = 6755399441055744.0 + 524288.0;
+    constexpr int SH = INTERP == kLinear ? kInterBits : 0;
+    constexpr int TAPS = INTERP == kLinear ? 1 : 0;  // extra tap to the right / below
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
+    if (item >= (uint32_t)a.total_tiles) return;
+    const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
+    const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;
+    const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;
+    const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h;
+    const int tid = threadIdx.x;
+    const uint8_t* __restrict__ frame = a.src + (int64_t)frame_idx * a.src_fs;
+    uint8_t* __restrict__ dframe = a.dst + (int64_t)frame_idx * a.dst_fs;
+    const double* __restrict__ M = a.minv + (int64_t)frame_idx * a.m_stride;
+    double Mr[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Mr[i] = M[i];
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lxi = lane & (kLX - 1), lyi = lane >> 4;
+    const int xg = x0 + lxi * PPL;
+    const int tile_bx = (int)(fast_div((uint32_t)x0, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+    double mx[PPL], my[PPL], mw[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+        const double x1 = (double)(xg + j - tile_bx);
+        mx[j] = Mr[0] * x1;
+        my[j] = Mr[3] * x1;
+        mw[j] = Mr[6] * x1;
+    }
+    const double bxd = (double)tile_bx;
+    const double bX = Mr[0] * bxd, bY = Mr[3] * bxd, bW = Mr[6] * bxd;
+    const int nvalid_x = max(0, min(PPL, a.dst_w - xg));
+    const int y_last = min(y0 + a.tile_h, a.dst_h) - 1;
+    const bool full_x = x0 + TW <= a.dst_w;  // uniform: every lane of the tile owns PPL real pixels
+    SrcView view;
+    view.frame = frame;
+    view.rs = a.src_rs;
+    view.w = a.src_w;
+    view.h = a.src_h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) view.bf[k] = a.bval_f[k];
+    view.bu = (uint32_t)a.bval_u8[0] | ((uint32_t)a.bval_u8[1] << 8) | ((uint32_t)a.bval_u8[2] << 16) | ((uint32_t)a.bval_u8[3] << 24);
+    const uint32_t rs32 = (uint32_t)a.src_rs;
+    uint8_t* slot = smem + (size_t)wave * a.lds_bytes;
+    const int slot_chunks = (a.lds_bytes >> 4) - 1;                  // one chunk of slack for the funnel read
+    const int row_chunk_bytes = (int)(((int64_t)a.src_w * PBs) & ~15);  // bytes of a row made of whole chunks
+
+    for (int yb = y0 + wave * kLY; yb <= y_last; yb += kBandRows) {  // wave-uniform
+        const bool row_valid = yb + lyi <= y_last;
+        const int y = min(yb + lyi, y_last);  // lanes below the tile recompute its last row (never stored)
+        // ---- coordinates (same chain as warp_gather)
+        const double dy = (double)y;
+        const double X0 = (bX + Mr[1] * dy) + Mr[2], Y0 = (bY + Mr[4] * dy) + Mr[5], W0 = (bW + Mr[7] * dy) + Mr[8];
+        double W[PPL], r[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) W[j] = W0 + mw[j];
+        if constexpr (PPL == 4) {
+            const double p01 = W[0] * W[1], p23 = W[2] * W[3];
+            const double inv = rcp_newton(p01 * p23) * kScale;
+            const double i01 = inv * p23, i23 = inv * p01;
+            r[0] = i01 * W[1];
+            r[1] = i01 * W[0];
+            r[2] = i23 * W[3];
+            r[3] = i23 * W[2];
+        } else {
+            const double inv = rcp_newton(W[0] * W[1]) * kScale;
+            r[0] = inv * W[1];
+            r[1] = inv * W[0];
+        }
+        const double wa = W[0], wb = W[PPL - 1];
+        const bool w_ok = (wa > 0) == (wb > 0) && fabs(wa) > 1e-60 && fabs(wa) < 1e60 && fabs(wb) > 1e-60 && fabs(wb) < 1e60;
+        int X[PPL], Y[PPL];
+        uint32_t tie = 0xffffffffu, expo = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+            const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
+            const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
+            X[j] = (int)(__builtin_amdgcn_alignbit(hix, lox, 20) ^ 0x80000000u);
+            Y[j] = (int)(__builtin_amdgcn_alignbit(hiy, loy, 20) ^ 0x80000000u);
+            tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+            expo |= (hix ^ 0x43300000u) | (hiy ^ 0x43300000u);
+        }
+        if (tie == 0 || (expo >> 20) != 0 || !w_ok) {  // rare: the exact chain decides
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
+                const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
+                const bool far = (uint32_t)(X[j] + (1 << 22)) >= (1u << 23) || (uint32_t)(Y[j] + (1 << 22)) >= (1u << 23);
+                if (!w_ok || far || ((lox + 2u) & 0xffffcu) == 0 || ((loy + 2u) & 0xffffcu) == 0 || ((hix ^ 0x43300000u) >> 20) != 0 ||
+                    ((hiy ^ 0x43300000u) >> 20) != 0)
+                    map_pixel_exact<INTERP>(X0 + mx[j], Y0 + my[j], W[j], X[j], Y[j]);
+            }
+        }
+        // ---- source box of the wave's block from its four corner pixels (+-1 px for rounding inside the block);
+        // the per-pixel test below makes correctness independent of this estimate.
+        const int cx[4] = {__builtin_amdgcn_readlane(X[0] >> SH, 0), __builtin_amdgcn_readlane(X[PPL - 1] >> SH, 15),
+                           __builtin_amdgcn_readlane(X[0] >> SH, 48), __builtin_amdgcn_readlane(X[PPL - 1] >> SH, 63)};
+        const int cy[4] = {__builtin_amdgcn_readlane(Y[0] >> SH, 0), __builtin_amdgcn_readlane(Y[PPL - 1] >> SH, 15),
+                           __builtin_amdgcn_readlane(Y[0] >> SH, 48), __builtin_amdgcn_readlane(Y[PPL - 1] >> SH, 63)};
+        const int rx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3])) - 1, rx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3])) + 1 + TAPS;
+        const int ry0 = min(min(cy[0], cy[1]), min(cy[2], cy[3])) - 1, ry1 = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1 + TAPS;
+        const int xb0 = (rx0 * PBs) & ~15, xb1 = ((rx1 + 1) * PBs + 15) & ~15;
+        const int cpr = (xb1 - xb0) >> 4, rows = ry1 - ry0 + 1;
+        const int total = rows * cpr;
+        const bool staged = a.src_vec_ok && full_x && rx0 >= 0 && ry0 >= 0 && ry1 < a.src_h && xb1 <= row_chunk_bytes && rx1 - rx0 < 4096 &&
+                            rows < 1024 && total <= slot_chunks;
+        Pixel<T, C> v[PPL];
+        if (staged) {
+            // ---- LDS-DMA: chunk c = (row r, column q) -> slot + 16 c; 64 chunks (1 KiB) per wave-instruction
+            const uint32_t mdiv = 0xffffffffu / (uint32_t)cpr + 1u;  // c / cpr == umulhi(c, mdiv) (c, cpr < 2^16)
+            const uint32_t gbase = (uint32_t)ry0 * rs32 + (uint32_t)xb0;
+            for (int c0 = 0; c0 < total; c0 += 64) {
+                const uint32_t c = (uint32_t)(c0 + lane);
+                if (c < (uint32_t)total) {
+                    const uint32_t rr = cpr == 1 ? c : __umulhi(c, mdiv), q = c - rr * (uint32_t)cpr;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(frame + (gbase + rr * rs32 + q * 16u)),
+                                                     (__attribute__((address_space(3))) void*)(slot + (size_t)c0 * 16), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA has landed; only this wave reads the slot
+            const uint32_t pitch = (uint32_t)cpr * 16u;
+            const uint32_t lim_x = (uint32_t)(rx1 - rx0 - TAPS), lim_y = (uint32_t)(ry1 - ry0 - TAPS);
+            uint32_t slow = 0;
+            Bytes<LOADB> t0[PPL], t1[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const int sx = X[j] >> SH, sy = Y[j] >> SH;
+                if ((uint32_t)(sx - rx0) <= lim_x && (uint32_t)(sy - ry0) <= lim_y) {
+                    const uint32_t A = (uint32_t)(sy - ry0) * pitch + (uint32_t)(sx * PBs - xb0);
+                    if constexpr (kFunnel) {
+                        const uint32_t* l0 = reinterpret_cast<const uint32_t*>(slot + (A & ~3u));
+                        const uint32_t* l1 = reinterpret_cast<const uint32_t*>(slot + (A & ~3u) + pitch);
+                        const uint32_t sh8 = (A & 3u) * 8u;
+                        uint32_t w0[LOADB / 4 + 1], w1[LOADB / 4 + 1];
+#pragma unroll
+                        for (int k = 0; k <= LOADB / 4; k++) {
+                            w0[k] = l0[k];
+                            if (INTERP == kLinear) w1[k] = l1[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < LOADB / 4; k++) {
+                            t0[j].w[k] = __builtin_amdgcn_alignbit(w0[k + 1], w0[k], sh8);
+                            if (INTERP == kLinear) t1[j].w[k] = __builtin_amdgcn_alignbit(w1[k + 1], w1[k], sh8);
+                        }
+                    } else {
+                        const uint32_t* l0 = reinterpret_cast<const uint32_t*>(slot + A);
+                        const uint32_t* l1 = reinterpret_cast<const uint32_t*>(slot + A + pitch);
+#pragma unroll
+                        for (int k = 0; k < LOADB / 4; k++) {
+                            t0[j].w[k] = l0[k];
+                            if (INTERP == kLinear) t1[j].w[k] = l1[k];
+                        }
+                    }
+                } else {
+                    slow |= 1u << j;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const uint32_t fx = (uint32_t)X[j] & 31u, fy = (uint32_t)Y[j] & 31u;
+                if constexpr (sizeof(T) == 1) {
+                    if (INTERP == kNearest) {
+                        v[j].packed = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+                    } else {
+                        uint32_t l0, r0, l1, r1;
+                        if constexpr (C == 4) {
+                            l0 = t0[j].w[0], r0 = t0[j].w[1], l1 = t1[j].w[0], r1 = t1[j].w[1];
+                        } else if constexpr (C == 3) {
+                            l0 = t0[j].w[0], r0 = __builtin_amdgcn_alignbyte(t0[j].w[1], t0[j].w[0], 3);
+                            l1 = t1[j].w[0], r1 = __builtin_amdgcn_alignbyte(t1[j].w[1], t1[j].w[0], 3);
+                        } else {
+                            l0 = t0[j].w[0], r0 = t0[j].w[0] >> (8 * C), l1 = t1[j].w[0], r1 = t1[j].w[0] >> (8 * C);
+                        }
+                        v[j].packed = blend_u8_packed<C>(l0, r0, l1, r1, fx, fy);
+                    }
+                } else {
+                    const float* f0 = reinterpret_cast<const float*>(&t0[j]);
+                    const float* f1 = reinterpret_cast<const float*>(&t1[j]);
+                    if (INTERP == kNearest) {
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = f0[k];
+                    } else {
+                        float w00, w01, w10, w11;
+                        weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                    }
+                }
+            }
+            if (slow) {  // never expected (the box bounds the block); kept so that correctness does not rest on it
+#pragma unroll
+                for (int j = 0; j < PPL; j++)
+                    if (slow & (1u << j)) v[j] = sample_global<T, C, INTERP>(view, X[j], Y[j]);
+            }
+        } else {
+            // ---- image border, ragged tiles, oversized or unaligned boxes: per-lane global sampling
+#pragma unroll
+            for (int j = 0; j < PPL; j++) v[j] = sample_global<T, C, INTERP>(view, X[j], Y[j]);
+        }
+        if (row_valid && nvalid_x > 0) store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
+    }
+}
+
 // Footprint: mark every in-bounds source pixel any tap would read (measurement aid; exact chain).
 template <int INTERP>
 __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch, int src_h, int src_w, int dst_h, int dst_w,
@@ -784,6 +1239,21 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
 
 template <typename T, int C>
 hipError_t launch_tc(const WarpArgs& a, int interp, dim3 grid, size_t lds, hipStream_t stream) {
+    if (a.gather == 2) {
+        const size_t wl = (size_t)a.lds_bytes * (kWG / 64);
+        if (interp == kNearest)
+            hipLaunchKernelGGL((warp_wave<T, C, kNearest>), grid, dim3(kWG), wl, stream, a);
+        else
+            hipLaunchKernelGGL((warp_wave<T, C, kLinear>), grid, dim3(kWG), wl, stream, a);
+        return hipGetLastError();
+    }
+    if (a.gather) {
+        if (interp == kNearest)
+            hipLaunchKernelGGL((warp_gather<T, C, kNearest>), grid, dim3(kWG), 0, stream, a);
+        else
+            hipLaunchKernelGGL((warp_gather<T, C, kLinear>), grid, dim3(kWG), 0, stream, a);
+        return hipGetLastError();
+    }
     if (interp == kNearest)
         hipLaunchKernelGGL((warp_tiles<T, C, kNearest>), grid, dim3(kWG), lds, stream, a);
     else

@@ -221,3 +221,28 @@ def test_config4_single_4k_frame(W):
     check(run_gpu(W, f, M, (dw, dh), 1), co.warp_perspective(f, M, (dw, dh), nthreads=8))
     Mb = wl.synth_brno_H(sw, sh, dw, dh)
     check(run_gpu(W, f, Mb, (dw, dh), 1), co.warp_perspective(f, Mb, (dw, dh), nthreads=8))
+
+
+# ---- the three kernels behind the same ABI (BEVWARP_MODE: 1 = LDS tiles per workgroup, 2 = direct gather,
+# ---- 3 = wave-private LDS tiles by LDS-DMA) must all reproduce the oracle; the default picks one of them.
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_every_kernel_variant_matches_oracle(W, monkeypatch, mode, dtype, interp):
+    monkeypatch.setenv("BEVWARP_MODE", mode)
+    cases = [("keystone", 1920, 1080, 1024, 1024), ("brno", 1280, 720, 512, 512), ("brno", 192, 108, 37, 53),
+             ("keystone", 856, 480, 300, 200), ("keystone", 100, 60, 300, 9)]
+    for kind, sw, sh, dw, dh in cases:
+        M = (wl.synth_brno_H if kind == "brno" else wl.keystone_H)(sw, sh, dw, dh)
+        src = wl.frame(2, sh, sw, dtype)
+        check(run_gpu(W, src, M, (dw, dh), interp), co.warp_perspective(src, M, (dw, dh), interp))
+    # 4-channel and 1-channel pixels, row-padded source view, border value
+    M = wl.synth_brno_H(640, 360, 160, 200)
+    for c in (1, 4):
+        src = wl.frame(3, 360, 640, dtype, c)
+        check(run_gpu(W, src, M, (160, 200), interp, border_value=9), co.warp_perspective(src, M, (160, 200), interp, border_value=9))
+    big = torch.from_numpy(wl.frame(7, 300, 640, dtype)).cuda()
+    view = big[:, 16:16 + 576]
+    Mv = wl.keystone_H(576, 300, 128, 96)
+    got = W.warp_perspective(view, Mv, (128, 96), flags=interp).cpu().numpy()
+    check(got, co.warp_perspective(np.ascontiguousarray(view.cpu().numpy()), Mv, (128, 96), interp))

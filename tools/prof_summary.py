@@ -28,7 +28,7 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcc"):
                 acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("== counters (%s): mean per dispatch" % sub)
         for k, d in acc.items():
-            if "warp_tiles" not in k:
+            if "warp_" not in k:
                 continue
             print("  " + k)
             for c, v in sorted(d.items()):
