@@ -127,19 +127,21 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     a.bw0 = block_width(dst_w, dst_h);
     // tile = tile_width x tile_h destination pixels per workgroup; the source box of a tile must fit
     // lds_bytes or the tile is redone in 16-row bands (tunable for experiments through the environment)
-    const int tw = tile_width(dtype);
     // two kernels: warp_tiles stages source tiles in LDS; warp_gather samples global memory directly and needs
     // every tile inside one evaluation block.  BEVWARP_MODE: 0 = pick (default), 1 = staged, 2 = gather.
     const int mode = env_int("BEVWARP_MODE", 0);
-    const bool gather_ok = (a.bw0 % tw == 0) || (a.bw0 >= dst_w);
-    // BEVWARP_MODE 3 = warp_wave (wave-private LDS tiles by LDS-DMA), same eligibility as gather
-    a.gather = !gather_ok ? 0 : (mode == 3 ? 2 : ((mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1))) ? 1 : 0));
+    // warp_gather needs a lane's pixels inside one evaluation block; warp_wave (mode 3) the whole 16-lane-wide tile
+    const bool lane_ok = (a.bw0 % pixels_per_lane_of(dtype) == 0) || (a.bw0 >= dst_w);
+    const bool tile_ok = (a.bw0 % tile_width(dtype, 2) == 0) || (a.bw0 >= dst_w);
+    a.gather = (mode == 3 && tile_ok) ? 2 : ((lane_ok && (mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1)))) ? 1 : 0);
+    const int tw = tile_width(dtype, a.gather);
     if (a.gather) {
-        a.tile_h = env_int("BEVWARP_GATHER_TILE_H", 64);
-        if (a.tile_h < 16 || a.tile_h > 1024 || a.tile_h % band_rows()) a.tile_h = 64;
+        const int dflt = band_rows(a.gather) * 4;  // four rows per lane
+        a.tile_h = env_int("BEVWARP_GATHER_TILE_H", dflt);
+        if (a.tile_h < band_rows(a.gather) || a.tile_h > 1024 || a.tile_h % band_rows(a.gather)) a.tile_h = dflt;
     } else {
         a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 32 : 16);
-        if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows()) a.tile_h = 16;
+        if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows(0)) a.tile_h = 16;
     }
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;

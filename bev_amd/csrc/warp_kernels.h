@@ -31,8 +31,9 @@ struct WarpArgs {
     uint8_t bval_u8[4];
 };
 
-int tile_width(int dtype);
-int band_rows();
+int tile_width(int dtype, int kernel);  // kernel: 0 = warp_tiles, 1 = warp_gather, 2 = warp_wave
+int band_rows(int kernel);
+int pixels_per_lane_of(int dtype);
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);

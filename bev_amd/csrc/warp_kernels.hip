@@ -35,6 +35,10 @@ constexpr int kLX = 16;                          // lanes along x inside a wave
 constexpr int kLY = 4;                           // lanes along y inside a wave
 constexpr int kBandRows = kLY * (kWG / 64);      // 16 rows per workgroup pass
 constexpr int kInterBits = 5;
+#ifndef BEVWARP_GATHER_LX
+#define BEVWARP_GATHER_LX 64
+#endif
+constexpr int kGatherLX = BEVWARP_GATHER_LX;     // warp_gather: lanes of a wave along x (64 = one row per wave)
 constexpr int kRowTabBytes = kMaxTileH * 3 * 8;  // per-row X0, Y0, W0 at the head of dynamic LDS
 
 template <typename T>
@@ -170,6 +174,19 @@ struct SrcView {
     float bf[4];
     uint32_t bu;  // border bytes packed
 };
+// 8-bit RGB straight from a tap window: (a1:a0) / (b1:b0) hold bytes 0..7 of the upper / lower source row starting
+// at the left tap (left pixel = bytes 0 1 2, right pixel = bytes 3 4 5); the byte selects do the unpacking.
+__device__ __forceinline__ uint32_t blend_u8_rgb_window(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t fx, uint32_t fy) {
+    const uint32_t wlo = fx * 255u + 32u, whi = wlo << 16;
+    const uint32_t wy1 = fy << 6, wy0 = 2048u - wy1;
+    const uint32_t t01 = __builtin_amdgcn_perm(a1, a0, 0x04010300u), u01 = __builtin_amdgcn_perm(b1, b0, 0x04010300u);  // L.c0 R.c0 L.c1 R.c1
+    const uint32_t t2 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0502u), u2 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0502u);    // L.c2 R.c2 0 0
+    const uint32_t s0 = __umul24(__builtin_amdgcn_udot4(t01, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u01, wlo, 0u, false), wy1) + 32768u);
+    const uint32_t s1 = __umul24(__builtin_amdgcn_udot4(t01, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u01, whi, 0u, false), wy1) + 32768u);
+    const uint32_t s2 = __umul24(__builtin_amdgcn_udot4(t2, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u2, wlo, 0u, false), wy1) + 32768u);
+    return __builtin_amdgcn_perm(s2, __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), 0x0c060100u);
+}
+
 template <typename T>
 __device__ __forceinline__ T border_of(const SrcView& a, int k);
 template <>
@@ -795,7 +812,8 @@ struct Bytes {
 template <typename T, int C, int INTERP>
 __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
-    constexpr int TW = kLX * PPL;
+    constexpr int GX = kGatherLX, GY = 64 / kGatherLX, GROWS = GY * (kWG / 64);  // lanes along x / y, rows per pass
+    constexpr int TW = GX * PPL;
     constexpr int PBs = (int)sizeof(T) * C;                      // source bytes per pixel
     constexpr int TAPB = INTERP == kLinear ? 2 * PBs : PBs;      // bytes of one row's taps
     constexpr int LOADB = (TAPB + 3) & ~3;                       // loaded per row (whole dwords)
@@ -818,9 +836,10 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
     for (int i = 0; i < 9; i++) Mr[i] = M[i];
 
     const int lane = tid & 63, wave = tid >> 6;
-    const int lxi = lane & (kLX - 1), lyi = lane >> 4;
+    const int lxi = lane % GX, lyi = lane / GX;
     const int xg = x0 + lxi * PPL;
-    const int tile_bx = (int)(fast_div((uint32_t)x0, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+    // evaluation block of THIS lane's pixels (a lane never straddles two: host checks bw0 % PPL == 0 or one block per row)
+    const int tile_bx = (int)(fast_div((uint32_t)min(xg, a.dst_w - 1), a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
     double mx[PPL], my[PPL], mw[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; j++) {
@@ -909,8 +928,12 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             const uint32_t off = (uint32_t)(Y[j] >> SH) * rs32 + (uint32_t)(X[j] >> SH) * (uint32_t)PBs;
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 1)  // diagnostic builds only: no tap loads
+            for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
+#else
             __builtin_memcpy(&t0[j], frame + off, LOADB);
-            if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + off + rs32, LOADB);
+            if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + (off + rs32), LOADB);
+#endif
         }
     };
     // -- blend (or border-sample) and store the row
@@ -934,7 +957,11 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                         } else {
                             l0 = t0[j].w[0], r0 = t0[j].w[0] >> (8 * C), l1 = t1[j].w[0], r1 = t1[j].w[0] >> (8 * C);
                         }
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 2)  // diagnostic builds only: no blend arithmetic
+                        v[j].packed = (l0 ^ r0 ^ l1 ^ r1) + fx + fy;
+#else
                         v[j].packed = blend_u8_packed<C>(l0, r0, l1, r1, fx, fy);  // bytes >= C of the taps are never selected
+#endif
                     }
                 } else {
                     const float* f0 = reinterpret_cast<const float*>(&t0[j]);
@@ -954,18 +981,157 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) v[j] = sample_global<T, C, INTERP>(view, X[j], Y[j]);
         }
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 4)  // diagnostic builds only: keep the values alive, store one row in 64
+        if ((y & 63) == 0)
+#endif
         store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
     };
 
-    // -- rows, software-pipelined: the loads of a row are in flight while the next row's coordinates are computed
-    int y = y0 + wave * kLY + lyi;
+    // -- tile classification, wave-uniform and computed redundantly by every wave (no LDS, no barrier): the
+    // tile's four corner pixels through the approximate chain.  A projective map with W of one sign sends the
+    // tile to a convex quadrilateral, so when the corners (+-2 px) sample strictly inside the frame every pixel
+    // of the tile does, W stays bounded away from zero, and the row loop needs no bounds / range / sign tests.
+    bool interior = false;
+    if (any_fast && x0 + TW <= a.dst_w && a.dst_vec_ok) {
+        const int cxp = (lane & 1) ? x0 + TW - 1 : x0, cyp = (lane & 2) ? y_last : y0;
+        const int cbx = (int)(fast_div((uint32_t)cxp, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
+        double cX0, cY0, cW0;
+        row_terms(Mr, cbx, cyp, cX0, cY0, cW0);
+        const double cx1 = (double)(cxp - cbx);
+        const double cW = cW0 + Mr[6] * cx1;
+        const double crc = rcp_newton(cW);
+        const double cpx = (cX0 + Mr[0] * cx1) * crc, cpy = (cY0 + Mr[3] * cx1) * crc;
+        const bool fin = fabs(cpx) < 1e9 && fabs(cpy) < 1e9 && fabs(cW) > 1e-60 && fabs(cW) < 1e60;
+        const int ix = fin ? (int)floor(cpx) : -(1 << 30), iy = fin ? (int)floor(cpy) : -(1 << 30);
+        const int sg = fin ? (cW > 0 ? 1 : -1) : 0;
+        int mnx = 1 << 30, mxx = -(1 << 30), mny = 1 << 30, mxy = -(1 << 30), sgs = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int kx = __builtin_amdgcn_readlane(ix, k), ky = __builtin_amdgcn_readlane(iy, k);
+            mnx = min(mnx, kx), mxx = max(mxx, kx), mny = min(mny, ky), mxy = max(mxy, ky);
+            sgs += __builtin_amdgcn_readlane(sg, k);
+        }
+        // exact sx lies in [floor(p) - 1, floor(p) + 1]; +-2 more for the approximate corner chain
+        interior = (sgs == 4 || sgs == -4) && mnx - 3 >= 0 && mny - 3 >= 0 && mxx + 3 <= sx_lim && mxy + 3 <= sy_lim;
+    }
+    if (interior) {
+        // raw coordinates carry + 2^31 (see row_fast); the byte offset absorbs it modulo 2^32
+        constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);
+        const uint32_t obias = 0u - kRawBias * rs32 - kRawBias * (uint32_t)PBs;
+        auto coords_f = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) {
+            const double dy = (double)y;
+            const double X0 = (bX + Mr[1] * dy) + Mr[2], Y0 = (bY + Mr[4] * dy) + Mr[5], W0 = (bW + Mr[7] * dy) + Mr[8];
+            double W[PPL], r[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) W[j] = W0 + mw[j];
+            if constexpr (PPL == 4) {
+                const double p01 = W[0] * W[1], p23 = W[2] * W[3];
+                const double inv = rcp_newton(p01 * p23) * kScale;
+                const double i01 = inv * p23, i23 = inv * p01;
+                r[0] = i01 * W[1];
+                r[1] = i01 * W[0];
+                r[2] = i23 * W[3];
+                r[3] = i23 * W[2];
+            } else {
+                const double inv = rcp_newton(W[0] * W[1]) * kScale;
+                r[0] = inv * W[1];
+                r[1] = inv * W[0];
+            }
+            uint32_t tie = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
+                RX[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(tx_), lox, 20);
+                RY[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(ty_), loy, 20);
+                tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+            }
+            if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                    if ((((uint32_t)__double2loint(tx_) + 2u) & 0xffffcu) == 0 || (((uint32_t)__double2loint(ty_) + 2u) & 0xffffcu) == 0) {
+                        int Xe, Ye;
+                        map_pixel_exact<INTERP>(X0 + mx[j], Y0 + my[j], W[j], Xe, Ye);
+                        RX[j] = (uint32_t)Xe ^ 0x80000000u;
+                        RY[j] = (uint32_t)Ye ^ 0x80000000u;
+                    }
+                }
+            }
+        };
+        auto issue_f = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const uint32_t off = (RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias);
+                __builtin_memcpy(&t0[j], frame + off, LOADB);
+                if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + (off + rs32), LOADB);
+            }
+        };
+        auto finish_f = [&](int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
+                            const Bytes<LOADB> (&t1)[PPL]) {
+            Pixel<T, C> v[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const uint32_t fx = RX[j] & 31u, fy = RY[j] & 31u;
+                if constexpr (sizeof(T) == 1) {
+                    if (INTERP == kNearest) {
+                        v[j].packed = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+                    } else if constexpr (C == 3) {
+                        v[j].packed = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                    } else if constexpr (C == 4) {
+                        v[j].packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                    } else {
+                        v[j].packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[0] >> (8 * C), t1[j].w[0], t1[j].w[0] >> (8 * C), fx, fy);
+                    }
+                } else {
+                    const float* f0 = reinterpret_cast<const float*>(&t0[j]);
+                    const float* f1 = reinterpret_cast<const float*>(&t1[j]);
+                    if (INTERP == kNearest) {
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = f0[k];
+                    } else {
+                        float w00, w01, w10, w11;
+                        weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
+#pragma unroll
+                        for (int k = 0; k < C; k++) v[j].v[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                    }
+                }
+            }
+            store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, PPL, v);
+        };
+        int yf = y0 + wave * GY + lyi;
+        if (yf > y_last) return;
+        uint32_t RXc[PPL], RYc[PPL];
+        Bytes<LOADB> u0[PPL], u1[PPL];
+        coords_f(yf, RXc, RYc);
+        issue_f(RXc, RYc, u0, u1);
+        for (;;) {
+            const int yn = yf + GROWS;
+            const bool has_next = yn <= y_last;
+            uint32_t RXn[PPL], RYn[PPL];
+            if (has_next) coords_f(yn, RXn, RYn);  // overlaps with the loads in flight
+            finish_f(yf, RXc, RYc, u0, u1);
+            if (!has_next) break;
+            issue_f(RXn, RYn, u0, u1);
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                RXc[j] = RXn[j];
+                RYc[j] = RYn[j];
+            }
+            yf = yn;
+        }
+        return;
+    }
+
+    // -- general rows (image border, ragged tiles), software-pipelined the same way
+    int y = y0 + wave * GY + lyi;
     if (y > y_last || nvalid_x == 0) return;
     int Xc[PPL], Yc[PPL];
     Bytes<LOADB> t0[PPL], t1[PPL];
     bool fc = coords(y, Xc, Yc);
     if (fc) issue(Xc, Yc, t0, t1);
     for (;;) {
-        const int yn = y + kBandRows;
+        const int yn = y + GROWS;
         const bool has_next = yn <= y_last;
         int Xn[PPL], Yn[PPL];
         bool fn = false;
@@ -1273,8 +1439,12 @@ hipError_t launch_t(const WarpArgs& a, int channels, int interp, dim3 grid, size
 
 }  // namespace
 
-int tile_width(int dtype) { return dtype == 0 ? kLX * pixels_per_lane<uint8_t>() : kLX * pixels_per_lane<float>(); }
-int band_rows() { return kBandRows; }
+int tile_width(int dtype, int kernel) {
+    const int ppl = dtype == 0 ? pixels_per_lane<uint8_t>() : pixels_per_lane<float>();
+    return (kernel == 1 ? kGatherLX : kLX) * ppl;
+}
+int band_rows(int kernel) { return kernel == 1 ? (64 / kGatherLX) * (kWG / 64) : kBandRows; }
+int pixels_per_lane_of(int dtype) { return dtype == 0 ? pixels_per_lane<uint8_t>() : pixels_per_lane<float>(); }
 
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream) {
     const dim3 grid((unsigned)(8 * a.chunk));
