@@ -92,8 +92,11 @@ def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
     }
 
 
-def load_traffic(dtype, interp):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+def load_traffic(dtype, interp, args):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None when the
+    workload is not the one that was profiled (configs[1] at its default shape)."""
+    if (args.batch, tuple(args.src), tuple(args.dst), args.homography) != (32, (1920, 1080), (1024, 1024), "keystone"):
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             return json.load(f).get("%s_%s" % (dtype, interp), {}).get("hbm_bytes_per_launch")
@@ -107,7 +110,7 @@ class Workload:
     def __init__(self, args, dtype, interp_name, rank, dev):
         from bev_amd import warp
         from tests import workloads as wl
-        self.warp, self.dtype, self.interp_name = warp, dtype, interp_name
+        self.warp, self.dtype, self.interp_name, self.args = warp, dtype, interp_name, args
         self.B = B = args.batch
         self.sw, self.sh = sw, sh = args.src
         self.dw, self.dh = dw, dh = args.dst
@@ -162,7 +165,7 @@ class Workload:
         kernel_s = float(launch_ms.mean()) / 1e3
         achieved = self.algo_bytes / kernel_s / 1e9
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(self.dtype, self.interp_name),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(self.dtype, self.interp_name, self.args),
                 "kernel": "warp_gather<%s,3,%s>" % ("uint8" if self.esz == 1 else "float", self.interp_name),
                 "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
                 "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
@@ -179,13 +182,17 @@ def main():
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    shard.init(backend="nccl", device=dev)  # no-op for one process; RCCL only carries the barrier / max below
+    # Rehearsal knobs for a 1-GPU box (never needed on a real node): BEV_BENCH_SAME_DEVICE=1 puts every rank on
+    # device 0 and BEV_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    dev_index = 0 if os.environ.get("BEV_BENCH_SAME_DEVICE") == "1" else local_rank
+    backend = os.environ.get("BEV_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    shard.init(backend=backend, device=dev)  # no-op for one process; RCCL only carries the barrier / max below
 
     main_wl = Workload(args, args.dtype, args.interp, rank, dev)
     elapsed, launch_ms = main_wl.run(args.steps, args.warmup, shard.barrier)
-    elapsed = shard.max_over_ranks(elapsed, dev)
+    elapsed = shard.max_over_ranks(elapsed)
 
     if rank == 0:
         B, dw, dh, sw, sh = main_wl.B, main_wl.dw, main_wl.dh, main_wl.sw, main_wl.sh
