@@ -820,6 +820,9 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
     constexpr double kScale = INTERP == kLinear ? 33554432.0 : 1048576.0;
     constexpr double kMagic = 6755399441055744.0 + 524288.0;
     constexpr int SH = INTERP == kLinear ? kInterBits : 0;
+    // float pixels whose per-lane chunk is not a multiple of 16 B go through a wave-private LDS row (interior path)
+    constexpr bool kTransposeStore = sizeof(T) == 4 && GY == 1 && ((PPL * C * 4) % 16) != 0 && ((64 * PPL * C) % 4) == 0;
+    __shared__ __attribute__((aligned(16))) float s_row[kTransposeStore ? kWG / 64 : 1][kTransposeStore ? 64 * PPL * C : 4];
 
     const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
     if (item >= (uint32_t)a.total_tiles) return;
@@ -1097,7 +1100,28 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                     }
                 }
             }
-            store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, PPL, v);
+            if constexpr (kTransposeStore) {
+                // A lane holds PPL*C floats (24 B for RGB): stored directly that is three 8-byte stores at a 24-byte
+                // lane stride (3x the TA time of contiguous stores, profiles/r01_ubench_mem.txt).  Transpose through a
+                // wave-private LDS row instead: lanes write their pixels, then each lane reads and stores 16
+                // CONSECUTIVE bytes of the wave's row segment.  Same-wave LDS ops execute in order: no barrier.
+                float* wrow = &s_row[wave][0];
+#pragma unroll
+                for (int j = 0; j < PPL; j++)
+#pragma unroll
+                    for (int k = 0; k < C; k++) wrow[lane * (PPL * C) + j * C + k] = v[j].v[k];
+                asm volatile("" ::: "memory");  // compiler fence only: one wave's LDS operations execute in program order
+                uint8_t* drow = dframe + (int64_t)y * a.dst_rs + (int64_t)(xg - lxi * PPL) * C * sizeof(T);  // start of the wave's segment
+                constexpr int kVec = 64 * PPL * C / 4;  // float4 units in the segment
+#pragma unroll
+                for (int u = 0; u < (kVec + 63) / 64; u++) {
+                    const int q = u * 64 + lane;
+                    if (q < kVec) reinterpret_cast<float4*>(drow)[q] = reinterpret_cast<const float4*>(wrow)[q];
+                }
+                asm volatile("" ::: "memory");  // (same: the next row's writes cannot pass these reads)
+            } else {
+                store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, PPL, v);
+            }
         };
         int yf = y0 + wave * GY + lyi;
         if (yf > y_last) return;
