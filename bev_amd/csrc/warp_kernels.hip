@@ -820,9 +820,9 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
     constexpr double kScale = INTERP == kLinear ? 33554432.0 : 1048576.0;
     constexpr double kMagic = 6755399441055744.0 + 524288.0;
     constexpr int SH = INTERP == kLinear ? kInterBits : 0;
-    // float pixels whose per-lane chunk is not a multiple of 16 B go through a wave-private LDS row (interior path)
-    constexpr bool kTransposeStore = sizeof(T) == 4 && GY == 1 && ((PPL * C * 4) % 16) != 0 && ((64 * PPL * C) % 4) == 0;
-    __shared__ __attribute__((aligned(16))) float s_row[kTransposeStore ? kWG / 64 : 1][kTransposeStore ? 64 * PPL * C : 4];
+    // wave-private LDS row used by the interior path to transpose results into store order (u8: one dword per
+    // pixel, float: C floats per pixel)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWG / 64][64 * PPL * (sizeof(T) == 1 ? 1 : C)];
 
     const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
     if (item >= (uint32_t)a.total_tiles) return;
@@ -1017,16 +1017,34 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
         // exact sx lies in [floor(p) - 1, floor(p) + 1]; +-2 more for the approximate corner chain
         interior = (sgs == 4 || sgs == -4) && mnx - 3 >= 0 && mny - 3 >= 0 && mxx + 3 <= sx_lim && mxy + 3 <= sy_lim;
     }
-    if (interior) {
-        // raw coordinates carry + 2^31 (see row_fast); the byte offset absorbs it modulo 2^32
-        constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);
+    if (interior && GY == 1 && a.bw0 == 64) {
+        // ---- interior tiles, lane-INTERLEAVED ownership: pixel j of lane l is x0 + 64 j + l, so one load instruction
+        // covers 64 consecutive destination pixels whose taps sit in a handful of cache lines (consecutive pixels per
+        // lane make the 4 loads of a row hit the same, still pending, lines: TCP pending stalls were 31 % of the
+        // kernel).  Pixel j lies in evaluation block j of the tile and x1 = l for every j.  Results are transposed to
+        // consecutive-per-lane order through a wave-private LDS row before the (contiguous) store.
+        constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);  // raw coordinates carry + 2^31
         const uint32_t obias = 0u - kRawBias * rs32 - kRawBias * (uint32_t)PBs;
-        auto coords_f = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) {
-            const double dy = (double)y;
-            const double X0 = (bX + Mr[1] * dy) + Mr[2], Y0 = (bY + Mr[4] * dy) + Mr[5], W0 = (bW + Mr[7] * dy) + Mr[8];
-            double W[PPL], r[PPL];
+        const double x1d = (double)lane;
+        const double mxs = Mr[0] * x1d, mys = Mr[3] * x1d, mws = Mr[6] * x1d;
+        double bXj[PPL], bYj[PPL], bWj[PPL];  // wave-uniform: M0 * bx_j ...
 #pragma unroll
-            for (int j = 0; j < PPL; j++) W[j] = W0 + mw[j];
+        for (int j = 0; j < PPL; j++) {
+            const double bj = (double)(x0 + 64 * j);
+            bXj[j] = Mr[0] * bj;
+            bYj[j] = Mr[3] * bj;
+            bWj[j] = Mr[6] * bj;
+        }
+        auto coords_s = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) {
+            const double dy = (double)y;
+            const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
+            double W[PPL], Xn[PPL], Yn[PPL], r[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                W[j] = ((bWj[j] + m7) + Mr[8]) + mws;
+                Xn[j] = ((bXj[j] + m1) + Mr[2]) + mxs;
+                Yn[j] = ((bYj[j] + m4) + Mr[5]) + mys;
+            }
             if constexpr (PPL == 4) {
                 const double p01 = W[0] * W[1], p23 = W[2] * W[3];
                 const double inv = rcp_newton(p01 * p23) * kScale;
@@ -1043,7 +1061,7 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
             uint32_t tie = 0xffffffffu;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                const double tx_ = Xn[j] * r[j] + kMagic, ty_ = Yn[j] * r[j] + kMagic;
                 const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
                 RX[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(tx_), lox, 20);
                 RY[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(ty_), loy, 20);
@@ -1052,17 +1070,17 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
             if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
 #pragma unroll
                 for (int j = 0; j < PPL; j++) {
-                    const double tx_ = (X0 + mx[j]) * r[j] + kMagic, ty_ = (Y0 + my[j]) * r[j] + kMagic;
+                    const double tx_ = Xn[j] * r[j] + kMagic, ty_ = Yn[j] * r[j] + kMagic;
                     if ((((uint32_t)__double2loint(tx_) + 2u) & 0xffffcu) == 0 || (((uint32_t)__double2loint(ty_) + 2u) & 0xffffcu) == 0) {
                         int Xe, Ye;
-                        map_pixel_exact<INTERP>(X0 + mx[j], Y0 + my[j], W[j], Xe, Ye);
+                        map_pixel_exact<INTERP>(Xn[j], Yn[j], W[j], Xe, Ye);
                         RX[j] = (uint32_t)Xe ^ 0x80000000u;
                         RY[j] = (uint32_t)Ye ^ 0x80000000u;
                     }
                 }
             }
         };
-        auto issue_f = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+        auto issue_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t off = (RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias);
@@ -1070,73 +1088,70 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                 if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + (off + rs32), LOADB);
             }
         };
-        auto finish_f = [&](int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
+        uint32_t* wtr = &s_tr[wave][0];
+        auto finish_s = [&](int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
                             const Bytes<LOADB> (&t1)[PPL]) {
-            Pixel<T, C> v[PPL];
+            uint8_t* drow = dframe + (int64_t)y * a.dst_rs + (int64_t)x0 * C * sizeof(T);  // the wave's row segment
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t fx = RX[j] & 31u, fy = RY[j] & 31u;
                 if constexpr (sizeof(T) == 1) {
+                    uint32_t px;
                     if (INTERP == kNearest) {
-                        v[j].packed = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+                        px = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
                     } else if constexpr (C == 3) {
-                        v[j].packed = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                        px = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
                     } else if constexpr (C == 4) {
-                        v[j].packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                        px = blend_u8_packed<C>(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
                     } else {
-                        v[j].packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[0] >> (8 * C), t1[j].w[0], t1[j].w[0] >> (8 * C), fx, fy);
+                        px = blend_u8_packed<C>(t0[j].w[0], t0[j].w[0] >> (8 * C), t1[j].w[0], t1[j].w[0] >> (8 * C), fx, fy);
                     }
+                    wtr[64 * j + lane] = px;
                 } else {
                     const float* f0 = reinterpret_cast<const float*>(&t0[j]);
                     const float* f1 = reinterpret_cast<const float*>(&t1[j]);
+                    float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
                     if (INTERP == kNearest) {
 #pragma unroll
-                        for (int k = 0; k < C; k++) v[j].v[k] = f0[k];
+                        for (int k = 0; k < C; k++) wf[k] = f0[k];
                     } else {
                         float w00, w01, w10, w11;
                         weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
 #pragma unroll
-                        for (int k = 0; k < C; k++) v[j].v[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                        for (int k = 0; k < C; k++) wf[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
                     }
                 }
             }
-            if constexpr (kTransposeStore) {
-                // A lane holds PPL*C floats (24 B for RGB): stored directly that is three 8-byte stores at a 24-byte
-                // lane stride (3x the TA time of contiguous stores, profiles/r01_ubench_mem.txt).  Transpose through a
-                // wave-private LDS row instead: lanes write their pixels, then each lane reads and stores 16
-                // CONSECUTIVE bytes of the wave's row segment.  Same-wave LDS ops execute in order: no barrier.
-                float* wrow = &s_row[wave][0];
-#pragma unroll
-                for (int j = 0; j < PPL; j++)
-#pragma unroll
-                    for (int k = 0; k < C; k++) wrow[lane * (PPL * C) + j * C + k] = v[j].v[k];
-                asm volatile("" ::: "memory");  // compiler fence only: one wave's LDS operations execute in program order
-                uint8_t* drow = dframe + (int64_t)y * a.dst_rs + (int64_t)(xg - lxi * PPL) * C * sizeof(T);  // start of the wave's segment
+            asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
+            if constexpr (sizeof(T) == 1) {
+                const uint4 q = reinterpret_cast<const uint4*>(wtr)[lane];  // pixels 4l .. 4l+3 of the segment
+                Pixel<T, C> v[PPL];
+                v[0].packed = q.x, v[1].packed = q.y, v[2].packed = q.z, v[3].packed = q.w;
+                store_pixels<T, C, PPL>(a, drow, lane * PPL, PPL, v);
+            } else {
                 constexpr int kVec = 64 * PPL * C / 4;  // float4 units in the segment
 #pragma unroll
                 for (int u = 0; u < (kVec + 63) / 64; u++) {
                     const int q = u * 64 + lane;
-                    if (q < kVec) reinterpret_cast<float4*>(drow)[q] = reinterpret_cast<const float4*>(wrow)[q];
+                    if (q < kVec) reinterpret_cast<float4*>(drow)[q] = reinterpret_cast<const float4*>(wtr)[q];
                 }
-                asm volatile("" ::: "memory");  // (same: the next row's writes cannot pass these reads)
-            } else {
-                store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, PPL, v);
             }
+            asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
         };
-        int yf = y0 + wave * GY + lyi;
+        int yf = y0 + wave;
         if (yf > y_last) return;
         uint32_t RXc[PPL], RYc[PPL];
         Bytes<LOADB> u0[PPL], u1[PPL];
-        coords_f(yf, RXc, RYc);
-        issue_f(RXc, RYc, u0, u1);
+        coords_s(yf, RXc, RYc);
+        issue_s(RXc, RYc, u0, u1);
         for (;;) {
             const int yn = yf + GROWS;
             const bool has_next = yn <= y_last;
             uint32_t RXn[PPL], RYn[PPL];
-            if (has_next) coords_f(yn, RXn, RYn);  // overlaps with the loads in flight
-            finish_f(yf, RXc, RYc, u0, u1);
+            if (has_next) coords_s(yn, RXn, RYn);  // overlaps with the loads in flight
+            finish_s(yf, RXc, RYc, u0, u1);
             if (!has_next) break;
-            issue_f(RXn, RYn, u0, u1);
+            issue_s(RXn, RYn, u0, u1);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 RXc[j] = RXn[j];

@@ -74,3 +74,29 @@ def test_rbox_iou_config5(dtype):
     dets = np.concatenate([a[:7], np.ones((7, 1))], axis=1)
     np.testing.assert_allclose(iou_batch_rbox(dets, b[:9]), exp[:7, :9], atol=1e-12)
     assert rbox_iou(torch.zeros((0, 5), device="cuda"), torch.zeros((3, 5), device="cuda")).shape == (0, 3)
+
+
+def test_composite_bev_img_matches_reference_arithmetic(golden):
+    """bev/tool/compo.py:26-49 (three warps + alpha blend) on the GPU vs oracle warps + the reference's numpy blend."""
+    from bev_amd.compo import composite_bev_img
+    from bev_amd.homo import homo_from_KRt
+    from tests import workloads as wl
+    k = golden["homo"]["KRt_in"]
+    K = np.array([[800.0, 0, 640.0], [0, 790.0, 360.0], [0, 0, 1.0]])
+    RT = np.array(k["T"])
+    rng = np.random.default_rng(3)
+    bg, fg = wl.frame(0, 720, 1280, np.uint8), wl.frame(1, 720, 1280, np.uint8)
+    mask = (rng.random((720, 1280, 1)) > 0.5).astype(np.uint8).repeat(3, 2) * 255
+    mask[100:200] = 128
+    H_world2bev = np.array([[0.0, 8.0, 160.0], [-8.0, 0.0, 500.0], [0.0, 0.0, 1.0]])
+    H_img2world_fix = np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)) @ np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])
+    got, Hcam = composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 320, 640)
+    np.testing.assert_allclose(Hcam, homo_from_KRt(K, Rt_homo=RT))
+    bg_b = co.warp_perspective(bg, H_world2bev.dot(H_img2world_fix), (320, 640)).astype(np.float64)
+    Hc = H_world2bev.dot(np.linalg.inv(Hcam))
+    fg_b = co.warp_perspective(fg, Hc, (320, 640)).astype(np.float64)
+    m_b = co.warp_perspective(mask, Hc, (320, 640)).astype(np.float64) / 255
+    exp = (fg_b * m_b + bg_b * (1 - m_b)).round()
+    exp[exp > 255] = 255
+    np.testing.assert_array_equal(got.cpu().numpy(), exp.astype(np.uint8))
+    assert got.shape == (640, 320, 3) and got.dtype == torch.uint8
