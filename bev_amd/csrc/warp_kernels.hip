@@ -809,6 +809,10 @@ struct Bytes {
     uint32_t w[N / 4];
 };
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T, int C, int INTERP>
 __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) Mr[i] = M[i];
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
     const int lxi = lane % GX, lyi = lane / GX;
     const int xg = x0 + lxi * PPL;
     // evaluation block of THIS lane's pixels (a lane never straddles two: host checks bw0 % PPL == 0 or one block per row)
@@ -1039,6 +1043,13 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
             const double dy = (double)y;
             const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
             double W[PPL], Xn[PPL], Yn[PPL], r[PPL];
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 8)  // diagnostic builds only: identity map instead of the projective chain
+            for (int j = 0; j < PPL; j++) {
+                RX[j] = 0x80000000u + ((uint32_t)(x0 + 64 * j + lane) << 5) + 7u + (uint32_t)(m1 > 1e300);
+                RY[j] = 0x80000000u + ((uint32_t)y << 5) + 9u;
+            }
+            return;
+#endif
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 W[j] = ((bWj[j] + m7) + Mr[8]) + mws;
@@ -1080,18 +1091,27 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                 }
             }
         };
+        const uint8_t* frame_r1 = frame + rs32;
         auto issue_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t off = (RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias);
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 1)  // diagnostic builds only: no tap loads
+                for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
+#else
                 __builtin_memcpy(&t0[j], frame + off, LOADB);
-                if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame + (off + rs32), LOADB);
+                if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame_r1 + off, LOADB);  // second tap row: same offset, base + row stride
+#endif
             }
         };
         uint32_t* wtr = &s_tr[wave][0];
-        auto finish_s = [&](int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
-                            const Bytes<LOADB> (&t1)[PPL]) {
-            uint8_t* drow = dframe + (int64_t)y * a.dst_rs + (int64_t)x0 * C * sizeof(T);  // the wave's row segment
+        // a finished row waits in registers (store order) until the NEXT row's loads have been issued: vmcnt
+        // retires in issue order, so a store issued before those loads would have to complete before their data
+        // can be used; issued after them it has a whole iteration to complete
+        constexpr int kVec = sizeof(T) == 1 ? 64 : 64 * PPL * C / 4;  // 16-byte units in the wave's row segment
+        constexpr int NQ = (kVec + 63) / 64;
+        auto finish_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
+                            const Bytes<LOADB> (&t1)[PPL], uint4 (&out)[NQ]) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t fx = RX[j] & 31u, fy = RY[j] & 31u;
@@ -1099,6 +1119,10 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                     uint32_t px;
                     if (INTERP == kNearest) {
                         px = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 2)  // diagnostic builds only: no blend arithmetic
+                    } else if constexpr (C == 3) {
+                        px = (t0[j].w[0] ^ t0[j].w[1] ^ t1[j].w[0] ^ t1[j].w[1]) + fx + fy;
+#endif
                     } else if constexpr (C == 3) {
                         px = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
                     } else if constexpr (C == 4) {
@@ -1123,42 +1147,72 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                 }
             }
             asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
-            if constexpr (sizeof(T) == 1) {
-                const uint4 q = reinterpret_cast<const uint4*>(wtr)[lane];  // pixels 4l .. 4l+3 of the segment
-                Pixel<T, C> v[PPL];
-                v[0].packed = q.x, v[1].packed = q.y, v[2].packed = q.z, v[3].packed = q.w;
-                store_pixels<T, C, PPL>(a, drow, lane * PPL, PPL, v);
-            } else {
-                constexpr int kVec = 64 * PPL * C / 4;  // float4 units in the segment
 #pragma unroll
-                for (int u = 0; u < (kVec + 63) / 64; u++) {
-                    const int q = u * 64 + lane;
-                    if (q < kVec) reinterpret_cast<float4*>(drow)[q] = reinterpret_cast<const float4*>(wtr)[q];
-                }
+            for (int u = 0; u < NQ; u++) {  // u8: pixels 4l .. 4l+3 of the segment; float: 16-byte unit u*64 + l
+                const int q = u * 64 + lane;
+                if (q < kVec) out[u] = reinterpret_cast<const uint4*>(wtr)[q];
             }
             asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
         };
+        // the destination is written once and never read back by this kernel: non-temporal stores keep it from
+        // displacing source lines in L2 / MALL (f32: -8 % kernel time)
+        auto store_s = [&](int y, const uint4 (&out)[NQ]) {
+            uint8_t* drow = dframe + (int64_t)y * a.dst_rs + (int64_t)x0 * C * sizeof(T);  // the wave's row segment
+#if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 4)  // diagnostic builds only: keep the values alive, store one row in 64
+            if ((y & 63) != 0 && out[0].x != 0x12345678u) return;
+#endif
+            if constexpr (sizeof(T) == 1) {  // the lane's 4 pixels = 4 C contiguous bytes, one instruction
+                uint8_t* d = drow + lane * (PPL * C);
+                const uint32_t p0 = out[0].x, p1 = out[0].y, p2 = out[0].z, p3 = out[0].w;
+                if constexpr (C == 1) {
+                    __builtin_nontemporal_store(p0 | (p1 << 8) | (p2 << 16) | (p3 << 24), reinterpret_cast<uint32_t*>(d));
+                } else if constexpr (C == 2) {
+                    u32x2 o = {p0 | (p1 << 16), p2 | (p3 << 16)};
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(d));
+                } else if constexpr (C == 3) {
+                    u32x3 o = {p0 | (p1 << 24), (p1 >> 8) | (p2 << 16), (p2 >> 16) | (p3 << 8)};
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(d));
+                } else {
+                    u32x4 o = {p0, p1, p2, p3};
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(d));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NQ; u++) {
+                    const int q = u * 64 + lane;
+                    u32x4 o = {out[u].x, out[u].y, out[u].z, out[u].w};
+                    if (q < kVec) __builtin_nontemporal_store(o, &reinterpret_cast<u32x4*>(drow)[q]);
+                }
+            }
+        };
+        // rows of a tile are dealt to its waves round-robin: neighbouring rows share source lines and run at the same time
         int yf = y0 + wave;
         if (yf > y_last) return;
-        uint32_t RXc[PPL], RYc[PPL];
+        uint32_t RXc[PPL], RYc[PPL], RXn[PPL], RYn[PPL];
         Bytes<LOADB> u0[PPL], u1[PPL];
+        uint4 out[NQ];
         coords_s(yf, RXc, RYc);
         issue_s(RXc, RYc, u0, u1);
-        for (;;) {
-            const int yn = yf + GROWS;
-            const bool has_next = yn <= y_last;
-            uint32_t RXn[PPL], RYn[PPL];
-            if (has_next) coords_s(yn, RXn, RYn);  // overlaps with the loads in flight
-            finish_s(yf, RXc, RYc, u0, u1);
-            if (!has_next) break;
-            issue_s(RXn, RYn, u0, u1);
+        // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt
+        // retires in issue order, so a store issued before a row's loads would have to reach L2 before that row's
+        // taps can be used; issued after them it has a whole iteration to complete.
+        bool more = yf + GROWS <= y_last;
+        if (more) coords_s(yf + GROWS, RXn, RYn);
+        finish_s(RXc, RYc, u0, u1, out);
+        while (more) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 RXc[j] = RXn[j];
                 RYc[j] = RYn[j];
             }
-            yf = yn;
+            issue_s(RXc, RYc, u0, u1);  // row yf + GROWS
+            store_s(yf, out);           // row yf
+            yf += GROWS;
+            more = yf + GROWS <= y_last;
+            if (more) coords_s(yf + GROWS, RXn, RYn);  // overlaps with the loads in flight
+            finish_s(RXc, RYc, u0, u1, out);
         }
+        store_s(yf, out);
         return;
     }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: parity tests + short benches; prints compact results.
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -4 gpurun_out/pytest_gpu.log
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "pytest exit $rc"; tail -4 gpurun_out/pytest_gpu.log
+[ $rc -ne 0 ] && exit 1   # no further GPU work after a failed (possibly faulting) test run
 for cfg in "u8 linear" "f32 linear" "u8 nearest"; do
   set -- $cfg
   python bench.py --steps 100 --warmup 10 --dtype $1 --interp $2 --no-cpu-baseline --no-variants "${@:3}" > gpurun_out/bench_$1_$2.json 2> gpurun_out/bench_$1_$2.err || tail -5 gpurun_out/bench_$1_$2.err
