@@ -813,8 +813,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// (register budget: 4 waves per SIMD for 8-bit pixels, 5 for float -- what the FAST row loop needs; the rare row
+// classes may spill)
 template <typename T, int C, int INTERP>
-__global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 4 : 5))) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int GX = kGatherLX, GY = 64 / kGatherLX, GROWS = GY * (kWG / 64);  // lanes along x / y, rows per pass
     constexpr int TW = GX * PPL;
@@ -994,39 +996,19 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
         store_pixels<T, C, PPL>(a, dframe + (int64_t)y * a.dst_rs, xg, nvalid_x, v);
     };
 
-    // -- tile classification, wave-uniform and computed redundantly by every wave (no LDS, no barrier): the
-    // tile's four corner pixels through the approximate chain.  A projective map with W of one sign sends the
-    // tile to a convex quadrilateral, so when the corners (+-2 px) sample strictly inside the frame every pixel
-    // of the tile does, W stays bounded away from zero, and the row loop needs no bounds / range / sign tests.
-    bool interior = false;
-    if (any_fast && x0 + TW <= a.dst_w && a.dst_vec_ok) {
-        const int cxp = (lane & 1) ? x0 + TW - 1 : x0, cyp = (lane & 2) ? y_last : y0;
-        const int cbx = (int)(fast_div((uint32_t)cxp, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
-        double cX0, cY0, cW0;
-        row_terms(Mr, cbx, cyp, cX0, cY0, cW0);
-        const double cx1 = (double)(cxp - cbx);
-        const double cW = cW0 + Mr[6] * cx1;
-        const double crc = rcp_newton(cW);
-        const double cpx = (cX0 + Mr[0] * cx1) * crc, cpy = (cY0 + Mr[3] * cx1) * crc;
-        const bool fin = fabs(cpx) < 1e9 && fabs(cpy) < 1e9 && fabs(cW) > 1e-60 && fabs(cW) < 1e60;
-        const int ix = fin ? (int)floor(cpx) : -(1 << 30), iy = fin ? (int)floor(cpy) : -(1 << 30);
-        const int sg = fin ? (cW > 0 ? 1 : -1) : 0;
-        int mnx = 1 << 30, mxx = -(1 << 30), mny = 1 << 30, mxy = -(1 << 30), sgs = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int kx = __builtin_amdgcn_readlane(ix, k), ky = __builtin_amdgcn_readlane(iy, k);
-            mnx = min(mnx, kx), mxx = max(mxx, kx), mny = min(mny, ky), mxy = max(mxy, ky);
-            sgs += __builtin_amdgcn_readlane(sg, k);
-        }
-        // exact sx lies in [floor(p) - 1, floor(p) + 1]; +-2 more for the approximate corner chain
-        interior = (sgs == 4 || sgs == -4) && mnx - 3 >= 0 && mny - 3 >= 0 && mxx + 3 <= sx_lim && mxy + 3 <= sy_lim;
-    }
-    if (interior && GY == 1 && a.bw0 == 64) {
-        // ---- interior tiles, lane-INTERLEAVED ownership: pixel j of lane l is x0 + 64 j + l, so one load instruction
-        // covers 64 consecutive destination pixels whose taps sit in a handful of cache lines (consecutive pixels per
-        // lane make the 4 loads of a row hit the same, still pending, lines: TCP pending stalls were 31 % of the
-        // kernel).  Pixel j lies in evaluation block j of the tile and x1 = l for every j.  Results are transposed to
-        // consecutive-per-lane order through a wave-private LDS row before the (contiguous) store.
+    // -- row-classified path: tiles that are a whole number of evaluation blocks wide.  Every row segment (TW pixels
+    // of one row) is classified on its own from its two end pixels: a projective map with W of one sign sends the
+    // segment to a straight segment of the source plane, so when both ends sample inside the frame (by a pixel of
+    // margin) every pixel does (FAST: no bounds / range / sign tests, unguarded loads), and when both ends lie beyond
+    // the same edge no pixel touches the frame (OUT: the border value).  When the frame's edge crosses the segment
+    // (EDGE) the coordinates of the fast chain still hold and only the pixels next to the edge take guarded taps;
+    // when W changes sign or is tiny, or coordinates pass 2^26 px (SLOW), the row takes the exact per-pixel chain.
+    if (GY == 1 && a.bw0 == 64 && any_fast && x0 + TW <= a.dst_w && a.dst_vec_ok) {
+        // lane-INTERLEAVED ownership: pixel j of lane l is x0 + 64 j + l, so one load instruction covers 64 consecutive
+        // destination pixels whose taps sit in a handful of cache lines.  Pixel j lies in evaluation block j of the
+        // tile and x1 = l for every j.  Results are transposed to consecutive-per-lane order through a wave-private
+        // LDS row before the (contiguous) store.
+        enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
         constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);  // raw coordinates carry + 2^31
         const uint32_t obias = 0u - kRawBias * rs32 - kRawBias * (uint32_t)PBs;
         const double x1d = (double)lane;
@@ -1039,7 +1021,12 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
             bYj[j] = Mr[3] * bj;
             bWj[j] = Mr[6] * bj;
         }
-        auto coords_s = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) {
+        // OUT rows may be filled with the border value when blending four border taps gives it back exactly:
+        // always for 8-bit (the fixed-point weights sum to 2^15) and nearest; for float bilinear only for +0
+        bool fill_ok = true;
+        if (sizeof(T) == 4 && INTERP == kLinear)
+            for (int k = 0; k < C; k++) fill_ok = fill_ok && __float_as_uint(a.bval_f[k]) == 0u;
+        auto coords_s = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) -> int {
             const double dy = (double)y;
             const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
             double W[PPL], Xn[PPL], Yn[PPL], r[PPL];
@@ -1048,7 +1035,7 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                 RX[j] = 0x80000000u + ((uint32_t)(x0 + 64 * j + lane) << 5) + 7u + (uint32_t)(m1 > 1e300);
                 RY[j] = 0x80000000u + ((uint32_t)y << 5) + 9u;
             }
-            return;
+            return kFast;
 #endif
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -1069,15 +1056,34 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                 r[0] = inv * W[1];
                 r[1] = inv * W[0];
             }
-            uint32_t tie = 0xffffffffu;
+            uint32_t tie = 0xffffffffu, hxa = 0, hya = 0, hxb = 0, hyb = 0;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const double tx_ = Xn[j] * r[j] + kMagic, ty_ = Yn[j] * r[j] + kMagic;
                 const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
-                RX[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(tx_), lox, 20);
-                RY[j] = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(ty_), loy, 20);
+                const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
+                RX[j] = __builtin_amdgcn_alignbit(hix, lox, 20);
+                RY[j] = __builtin_amdgcn_alignbit(hiy, loy, 20);
                 tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+                if (j == 0) hxa = hix, hya = hiy;
+                if (j == PPL - 1) hxb = hix, hyb = hiy;
             }
+            // -- classify the segment from its ends (pixel 0 of lane 0, pixel PPL-1 of lane 63), in scalar registers.
+            // The mantissa trick is valid while the sum keeps the magic's exponent (|coordinate| < 2^31 units).
+            auto lane_u32 = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };  // (the builtin returns int)
+            const uint32_t kExp = 0x43300000u;
+            const uint32_t e_bad = ((lane_u32(hxa, 0) ^ kExp) | (lane_u32(hya, 0) ^ kExp) | (lane_u32(hxb, 63) ^ kExp) | (lane_u32(hyb, 63) ^ kExp)) >> 20;
+            const uint32_t wa = lane_u32((uint32_t)__double2hiint(W[0]), 0), wb = lane_u32((uint32_t)__double2hiint(W[PPL - 1]), 63);
+            const uint32_t ea = (wa >> 20) & 0x7ffu, eb = (wb >> 20) & 0x7ffu;  // 2^-199 .. 2^199: the shared reciprocal is safe
+            const bool w_ok = ((wa ^ wb) >> 31) == 0 && ea - 824u <= 398u && eb - 824u <= 398u;
+            constexpr uint32_t kCoordBias = INTERP == kLinear ? (1u << 26) : (1u << 31);
+            const int sxa = (int)((lane_u32(RX[0], 0) >> SH) - kCoordBias), sya = (int)((lane_u32(RY[0], 0) >> SH) - kCoordBias);
+            const int sxb = (int)((lane_u32(RX[PPL - 1], 63) >> SH) - kCoordBias), syb = (int)((lane_u32(RY[PPL - 1], 63) >> SH) - kCoordBias);
+            const bool in = (uint32_t)(sxa - 1) <= (uint32_t)(sx_lim - 2) && (uint32_t)(sxb - 1) <= (uint32_t)(sx_lim - 2) &&
+                            (uint32_t)(sya - 1) <= (uint32_t)(sy_lim - 2) && (uint32_t)(syb - 1) <= (uint32_t)(sy_lim - 2) && sx_lim >= 2 && sy_lim >= 2;
+            const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
+            // kEdge: the coordinates are good, taps need guards
+            const int cls = !(e_bad == 0 && w_ok) ? kSlow : (in ? kFast : ((out && fill_ok) ? kOut : kEdge));
             if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
 #pragma unroll
                 for (int j = 0; j < PPL; j++) {
@@ -1090,12 +1096,15 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                     }
                 }
             }
+            return cls;
         };
         const uint8_t* frame_r1 = frame + rs32;
-        auto issue_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+        // (rows that are not FAST load from offset 0: the row loop keeps one shape for every class)
+        auto issue_s = [&](int cls, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+            const uint32_t keep = cls == kFast ? 0xffffffffu : 0u;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const uint32_t off = (RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias);
+                const uint32_t off = ((RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias)) & keep;
 #if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 1)  // diagnostic builds only: no tap loads
                 for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
 #else
@@ -1110,8 +1119,18 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
         // can be used; issued after them it has a whole iteration to complete
         constexpr int kVec = sizeof(T) == 1 ? 64 : 64 * PPL * C / 4;  // 16-byte units in the wave's row segment
         constexpr int NQ = (kVec + 63) / 64;
+        // LDS row -> registers in store order (u8: pixels 4l .. 4l+3 of the segment; float: 16-byte unit u*64 + l)
+        auto read_back = [&](uint4 (&out)[NQ]) {
+            asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
+#pragma unroll
+            for (int u = 0; u < NQ; u++) {
+                const int q = u * 64 + lane;
+                if (q < kVec) out[u] = reinterpret_cast<const uint4*>(wtr)[q];
+            }
+            asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
+        };
         auto finish_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
-                            const Bytes<LOADB> (&t1)[PPL], uint4 (&out)[NQ]) {
+                            const Bytes<LOADB> (&t1)[PPL]) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t fx = RX[j] & 31u, fy = RY[j] & 31u;
@@ -1146,13 +1165,111 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
                     }
                 }
             }
-            asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
+        };
+        // the other row classes fill the LDS row their own way
+        // OUT row: the border value
+        auto fill_s = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < NQ; u++) {  // u8: pixels 4l .. 4l+3 of the segment; float: 16-byte unit u*64 + l
-                const int q = u * 64 + lane;
-                if (q < kVec) out[u] = reinterpret_cast<const uint4*>(wtr)[q];
+            for (int j = 0; j < PPL; j++) {
+                if constexpr (sizeof(T) == 1) {
+                    wtr[64 * j + lane] = C == 4 ? view.bu : (view.bu & ((1u << (8 * (C & 3))) - 1u));
+                } else {
+                    float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
+#pragma unroll
+                    for (int k = 0; k < C; k++) wf[k] = view.bf[k];
+                }
             }
-            asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
+        };
+        // SLOW row: exact chain and guarded taps for each of the lane's pixels (same ownership, same store order)
+        auto slow_s = [&](int y) __attribute__((always_inline)) {
+            const double dy = (double)y;
+            const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const double Wj = ((bWj[j] + m7) + Mr[8]) + mws, Xj = ((bXj[j] + m1) + Mr[2]) + mxs, Yj = ((bYj[j] + m4) + Mr[5]) + mys;
+                int Xe, Ye;
+                map_pixel_exact<INTERP>(Xj, Yj, Wj, Xe, Ye);
+                const Pixel<T, C> v = sample_global<T, C, INTERP>(view, Xe, Ye);
+                if constexpr (sizeof(T) == 1) {
+                    wtr[64 * j + lane] = v.packed;
+                } else {
+                    float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
+#pragma unroll
+                    for (int k = 0; k < C; k++) wf[k] = v.v[k];
+                }
+            }
+        };
+        // EDGE row: unguarded window loads + the fast blend for the pixels whose taps are inside, the border value for
+        // those whose taps are all outside, guarded taps for the few in between
+        auto edge_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) __attribute__((always_inline)) {
+            int X[PPL], Y[PPL];  // (t0, t1: the pipeline's tap registers, idle for a row that is not FAST)
+            bool inb[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                X[j] = (int)(RX[j] ^ 0x80000000u), Y[j] = (int)(RY[j] ^ 0x80000000u);
+                const int sx = X[j] >> SH, sy = Y[j] >> SH;
+                inb[j] = (uint32_t)sx <= sx_max && (uint32_t)sy <= sy_max;
+                const uint32_t off = inb[j] ? (uint32_t)sy * rs32 + (uint32_t)sx * (uint32_t)PBs : 0u;  // (0: any in-bounds address)
+                __builtin_memcpy(&t0[j], frame + off, LOADB);
+                if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame_r1 + off, LOADB);
+            }
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const int sx = X[j] >> SH, sy = Y[j] >> SH;
+                const uint32_t fx = (uint32_t)X[j] & 31u, fy = (uint32_t)Y[j] & 31u;
+                constexpr int kTap = INTERP == kLinear ? 1 : 0;  // taps reach sx + kTap, sy + kTap
+                const bool all_out = fill_ok && (sx < -kTap || sx >= a.src_w || sy < -kTap || sy >= a.src_h);
+                Pixel<T, C> v;
+                if (inb[j]) {
+                    if constexpr (sizeof(T) == 1) {
+                        if (INTERP == kNearest)
+                            v.packed = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
+                        else if constexpr (C == 3)
+                            v.packed = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                        else if constexpr (C == 4)
+                            v.packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
+                        else
+                            v.packed = blend_u8_packed<C>(t0[j].w[0], t0[j].w[0] >> (8 * C), t1[j].w[0], t1[j].w[0] >> (8 * C), fx, fy);
+                    } else {
+                        const float* f0 = reinterpret_cast<const float*>(&t0[j]);
+                        const float* f1 = reinterpret_cast<const float*>(&t1[j]);
+                        float w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+                        if (INTERP == kLinear) weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
+#pragma unroll
+                        for (int k = 0; k < C; k++) v.v[k] = INTERP == kNearest ? f0[k] : blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                    }
+                } else if (all_out) {
+                    if constexpr (sizeof(T) == 1) {
+                        v.packed = C == 4 ? view.bu : (view.bu & ((1u << (8 * (C & 3))) - 1u));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < C; k++) v.v[k] = view.bf[k];
+                    }
+                } else {
+                    v = sample_global<T, C, INTERP>(view, X[j], Y[j]);
+                }
+                if constexpr (sizeof(T) == 1) {
+                    wtr[64 * j + lane] = v.packed;
+                } else {
+                    float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
+#pragma unroll
+                    for (int k = 0; k < C; k++) wf[k] = v.v[k];
+                }
+            }
+        };
+        auto finish_any = [&](int cls, int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL],
+                              Bytes<LOADB> (&t1)[PPL], uint4 (&out)[NQ]) {
+            if (__builtin_expect(cls == kFast, 1)) {
+                finish_s(RX, RY, t0, t1);
+            } else {
+                if (cls == kOut)
+                    fill_s();
+                else if (cls == kEdge)
+                    edge_s(RX, RY, t0, t1);
+                else
+                    slow_s(y);
+            }
+            read_back(out);
         };
         // the destination is written once and never read back by this kernel: non-temporal stores keep it from
         // displacing source lines in L2 / MALL (f32: -8 % kernel time)
@@ -1191,26 +1308,27 @@ __global__ __launch_bounds__(kWG) void warp_gather(const WarpArgs a) {
         uint32_t RXc[PPL], RYc[PPL], RXn[PPL], RYn[PPL];
         Bytes<LOADB> u0[PPL], u1[PPL];
         uint4 out[NQ];
-        coords_s(yf, RXc, RYc);
-        issue_s(RXc, RYc, u0, u1);
+        int cls_c = coords_s(yf, RXc, RYc), cls_n = kSlow;
+        issue_s(cls_c, RXc, RYc, u0, u1);
         // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt
         // retires in issue order, so a store issued before a row's loads would have to reach L2 before that row's
         // taps can be used; issued after them it has a whole iteration to complete.
         bool more = yf + GROWS <= y_last;
-        if (more) coords_s(yf + GROWS, RXn, RYn);
-        finish_s(RXc, RYc, u0, u1, out);
+        if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);
+        finish_any(cls_c, yf, RXc, RYc, u0, u1, out);
         while (more) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 RXc[j] = RXn[j];
                 RYc[j] = RYn[j];
             }
-            issue_s(RXc, RYc, u0, u1);  // row yf + GROWS
-            store_s(yf, out);           // row yf
+            cls_c = cls_n;
+            issue_s(cls_c, RXc, RYc, u0, u1);  // row yf + GROWS
+            store_s(yf, out);                  // row yf
             yf += GROWS;
             more = yf + GROWS <= y_last;
-            if (more) coords_s(yf + GROWS, RXn, RYn);  // overlaps with the loads in flight
-            finish_s(RXc, RYc, u0, u1, out);
+            if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);  // overlaps with the loads in flight
+            finish_any(cls_c, yf, RXc, RYc, u0, u1, out);
         }
         store_s(yf, out);
         return;
