@@ -53,7 +53,7 @@ const char* bevwarp_strerror(int status) {
         case BEVWARP_OK: return "ok";
         case BEVWARP_ERR_BAD_ARG: return "bad argument (null pointer, non-positive size or misaligned stride)";
         case BEVWARP_ERR_UNSUPPORTED: return "unsupported dtype / channel count / interpolation";
-        case BEVWARP_ERR_TOO_LARGE: return "source image side exceeds 32767 px or a frame exceeds 2 GiB";
+        case BEVWARP_ERR_TOO_LARGE: return "source image side exceeds 32767 px, a row 16 MiB or a frame 2 GiB";
         case BEVWARP_ERR_NOT_FINITE: return "homography contains NaN or Inf";
         case BEVWARP_ERR_HIP: return "HIP runtime error (see bevwarp_last_hip_error)";
         default: return "unknown status";
@@ -106,7 +106,7 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
         ((uintptr_t)src % esz) || ((uintptr_t)dst % esz))
         return BEVWARP_ERR_BAD_ARG;
     if (src_w > 32767 || src_h > 32767) return BEVWARP_ERR_TOO_LARGE;
-    if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31)) return BEVWARP_ERR_TOO_LARGE;
+    if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31) || src_row_stride >= (1 << 24)) return BEVWARP_ERR_TOO_LARGE;  // (kernels use 24-bit multiplies)
     if (batch == 0) return BEVWARP_OK;
 
     WarpArgs a;

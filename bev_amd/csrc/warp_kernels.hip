@@ -804,6 +804,9 @@ namespace {
 // LDS: occupancy is bounded by registers only and a wave keeps all the loads of its PPL pixels in
 // flight.  Requires every TW-wide tile to lie in one evaluation block (host checks).
 // ===================================================================================================
+#ifndef BEVWARP_F32_WAVES
+#define BEVWARP_F32_WAVES 4
+#endif
 template <int N>
 struct Bytes {
     uint32_t w[N / 4];
@@ -813,10 +816,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// (register budget: 4 waves per SIMD for 8-bit pixels, 5 for float -- what the FAST row loop needs; the rare row
+// (register budget: 4 waves per SIMD -- what the FAST row loop needs without spilling; the rare row
 // classes may spill)
 template <typename T, int C, int INTERP>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 4 : 5))) void warp_gather(const WarpArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 4 : BEVWARP_F32_WAVES))) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int GX = kGatherLX, GY = 64 / kGatherLX, GROWS = GY * (kWG / 64);  // lanes along x / y, rows per pass
     constexpr int TW = GX * PPL;
@@ -1009,39 +1012,53 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         // tile and x1 = l for every j.  Results are transposed to consecutive-per-lane order through a wave-private
         // LDS row before the (contiguous) store.
         enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
-        constexpr uint32_t kRawBias = INTERP == kLinear ? (1u << 26) : (1u << 31);  // raw coordinates carry + 2^31
-        const uint32_t obias = 0u - kRawBias * rs32 - kRawBias * (uint32_t)PBs;
+        // Row terms.  The reference's chain is X0 = (M0*bx + M1*y) + M2, X = X0 + M0*(x - bx) per evaluation block;
+        // the fast chain below only has to land within 2^-20 of a coordinate unit of it (anything closer than
+        // 2^-19 to a rounding boundary is redone exactly), which leaves ~12 bits of slack over float64 rounding.
+        // So a row evaluates the chain once, for the segment's first pixel (UX, UY, UW: wave-uniform), and adds
+        // per-lane constants M0*(64 j + lane): 22 operations per row instead of 40.  exact_px() restates the
+        // reference's order of operations for the rare exact redo.
         const double x1d = (double)lane;
-        const double mxs = Mr[0] * x1d, mys = Mr[3] * x1d, mws = Mr[6] * x1d;
-        double bXj[PPL], bYj[PPL], bWj[PPL];  // wave-uniform: M0 * bx_j ...
+        double cxj[PPL], cyj[PPL], cwj[PPL];
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            const double bj = (double)(x0 + 64 * j);
-            bXj[j] = Mr[0] * bj;
-            bYj[j] = Mr[3] * bj;
-            bWj[j] = Mr[6] * bj;
+            const double dj = (double)(64 * j + lane);
+            cxj[j] = Mr[0] * dj;
+            cyj[j] = Mr[3] * dj;
+            cwj[j] = Mr[6] * dj;
         }
+        auto uniform_f64 = [](double v) {  // a wave-uniform double, moved to scalar registers
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        };
+        const double bX0 = uniform_f64(Mr[0] * (double)x0), bY0 = uniform_f64(Mr[3] * (double)x0), bW0 = uniform_f64(Mr[6] * (double)x0);
+        auto exact_px = [&](int y, int j, double& Xn, double& Yn, double& Wn) __attribute__((always_inline)) {
+            double X0, Y0, W0;
+            row_terms(Mr, x0 + 64 * j, y, X0, Y0, W0);
+            Xn = X0 + Mr[0] * x1d;
+            Yn = Y0 + Mr[3] * x1d;
+            Wn = W0 + Mr[6] * x1d;
+        };
         // OUT rows may be filled with the border value when blending four border taps gives it back exactly:
         // always for 8-bit (the fixed-point weights sum to 2^15) and nearest; for float bilinear only for +0
         bool fill_ok = true;
         if (sizeof(T) == 4 && INTERP == kLinear)
             for (int k = 0; k < C; k++) fill_ok = fill_ok && __float_as_uint(a.bval_f[k]) == 0u;
         auto coords_s = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) -> int {
-            const double dy = (double)y;
-            const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
             double W[PPL], Xn[PPL], Yn[PPL], r[PPL];
+            const double dy = (double)y;
+            const double UX = (bX0 + Mr[1] * dy) + Mr[2], UY = (bY0 + Mr[4] * dy) + Mr[5], UW = (bW0 + Mr[7] * dy) + Mr[8];
 #if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 8)  // diagnostic builds only: identity map instead of the projective chain
             for (int j = 0; j < PPL; j++) {
-                RX[j] = 0x80000000u + ((uint32_t)(x0 + 64 * j + lane) << 5) + 7u + (uint32_t)(m1 > 1e300);
+                RX[j] = 0x80000000u + ((uint32_t)(x0 + 64 * j + lane) << 5) + 7u + (uint32_t)(UX > 1e300);
                 RY[j] = 0x80000000u + ((uint32_t)y << 5) + 9u;
             }
             return kFast;
 #endif
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                W[j] = ((bWj[j] + m7) + Mr[8]) + mws;
-                Xn[j] = ((bXj[j] + m1) + Mr[2]) + mxs;
-                Yn[j] = ((bYj[j] + m4) + Mr[5]) + mys;
+                W[j] = UW + cwj[j];
+                Xn[j] = UX + cxj[j];
+                Yn[j] = UY + cyj[j];
             }
             if constexpr (PPL == 4) {
                 const double p01 = W[0] * W[1], p23 = W[2] * W[3];
@@ -1059,12 +1076,14 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             uint32_t tie = 0xffffffffu, hxa = 0, hya = 0, hxb = 0, hyb = 0;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const double tx_ = Xn[j] * r[j] + kMagic, ty_ = Yn[j] * r[j] + kMagic;
+                // kMagic + 2: the low word then reads (fraction + 2) and one mask tests the window [-2, 2) around a
+                // rounding boundary; outside that window the extra 2 does not change the integer part
+                const double tx_ = Xn[j] * r[j] + (kMagic + 2.0), ty_ = Yn[j] * r[j] + (kMagic + 2.0);
                 const uint32_t lox = (uint32_t)__double2loint(tx_), loy = (uint32_t)__double2loint(ty_);
                 const uint32_t hix = (uint32_t)__double2hiint(tx_), hiy = (uint32_t)__double2hiint(ty_);
                 RX[j] = __builtin_amdgcn_alignbit(hix, lox, 20);
                 RY[j] = __builtin_amdgcn_alignbit(hiy, loy, 20);
-                tie = min(tie, min((lox + 2u) & 0xffffcu, (loy + 2u) & 0xffffcu));
+                tie = min(tie, min(lox & 0xffffcu, loy & 0xffffcu));
                 if (j == 0) hxa = hix, hya = hiy;
                 if (j == PPL - 1) hxb = hix, hyb = hiy;
             }
@@ -1087,10 +1106,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
 #pragma unroll
                 for (int j = 0; j < PPL; j++) {
-                    const double tx_ = Xn[j] * r[j] + kMagic, ty_ = Yn[j] * r[j] + kMagic;
-                    if ((((uint32_t)__double2loint(tx_) + 2u) & 0xffffcu) == 0 || (((uint32_t)__double2loint(ty_) + 2u) & 0xffffcu) == 0) {
+                    const double tx_ = Xn[j] * r[j] + (kMagic + 2.0), ty_ = Yn[j] * r[j] + (kMagic + 2.0);
+                    if (((uint32_t)__double2loint(tx_) & 0xffffcu) == 0 || ((uint32_t)__double2loint(ty_) & 0xffffcu) == 0) {
+                        double Xq, Yq, Wq;
+                        exact_px(y, j, Xq, Yq, Wq);
                         int Xe, Ye;
-                        map_pixel_exact<INTERP>(Xn[j], Yn[j], W[j], Xe, Ye);
+                        map_pixel_exact<INTERP>(Xq, Yq, Wq, Xe, Ye);
                         RX[j] = (uint32_t)Xe ^ 0x80000000u;
                         RY[j] = (uint32_t)Ye ^ 0x80000000u;
                     }
@@ -1101,10 +1122,13 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const uint8_t* frame_r1 = frame + rs32;
         // (rows that are not FAST load from offset 0: the row loop keeps one shape for every class)
         auto issue_s = [&](int cls, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
-            const uint32_t keep = cls == kFast ? 0xffffffffu : 0u;
+            // FAST rows sample inside the frame: 0 <= sx, sy < 2^15, so 16-bit fields drop the 2^31 bias and 24-bit
+            // multiplies build the byte offset (the host guarantees row stride < 2^24 and frames < 2 GiB)
+            const uint32_t rs_eff = cls == kFast ? rs32 : 0u, pb_eff = cls == kFast ? (uint32_t)PBs : 0u;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const uint32_t off = ((RY[j] >> SH) * rs32 + ((RX[j] >> SH) * (uint32_t)PBs + obias)) & keep;
+                const uint32_t sx = __builtin_amdgcn_ubfe(RX[j], SH, 16), sy = __builtin_amdgcn_ubfe(RY[j], SH, 16);
+                const uint32_t off = __umul24(sy, rs_eff) + __umul24(sx, pb_eff);
 #if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 1)  // diagnostic builds only: no tap loads
                 for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
 #else
@@ -1182,11 +1206,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         };
         // SLOW row: exact chain and guarded taps for each of the lane's pixels (same ownership, same store order)
         auto slow_s = [&](int y) __attribute__((always_inline)) {
-            const double dy = (double)y;
-            const double m1 = Mr[1] * dy, m4 = Mr[4] * dy, m7 = Mr[7] * dy;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const double Wj = ((bWj[j] + m7) + Mr[8]) + mws, Xj = ((bXj[j] + m1) + Mr[2]) + mxs, Yj = ((bYj[j] + m4) + Mr[5]) + mys;
+                double Xj, Yj, Wj;
+                exact_px(y, j, Xj, Yj, Wj);
                 int Xe, Ye;
                 map_pixel_exact<INTERP>(Xj, Yj, Wj, Xe, Ye);
                 const Pixel<T, C> v = sample_global<T, C, INTERP>(view, Xe, Ye);
