@@ -20,6 +20,7 @@
 // No MFMA: this is a gather.  The 8-bit kernel is bound by vector-ALU issue (float64 coordinate
 // chain + blending), the float kernel by HBM.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <type_traits>
 
@@ -1637,6 +1638,12 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
         }
 }
 
+// experiments only: BEVWARP_GATHER_PAD_LDS=<bytes> of unused dynamic LDS per workgroup lowers warp_gather's occupancy
+inline size_t gather_pad_lds() {
+    const char* e = getenv("BEVWARP_GATHER_PAD_LDS");
+    return e ? (size_t)atoi(e) : 0;
+}
+
 template <typename T, int C>
 hipError_t launch_tc(const WarpArgs& a, int interp, dim3 grid, size_t lds, hipStream_t stream) {
     if (a.gather == 2) {
@@ -1649,9 +1656,9 @@ hipError_t launch_tc(const WarpArgs& a, int interp, dim3 grid, size_t lds, hipSt
     }
     if (a.gather) {
         if (interp == kNearest)
-            hipLaunchKernelGGL((warp_gather<T, C, kNearest>), grid, dim3(kWG), 0, stream, a);
+            hipLaunchKernelGGL((warp_gather<T, C, kNearest>), grid, dim3(kWG), gather_pad_lds(), stream, a);
         else
-            hipLaunchKernelGGL((warp_gather<T, C, kLinear>), grid, dim3(kWG), 0, stream, a);
+            hipLaunchKernelGGL((warp_gather<T, C, kLinear>), grid, dim3(kWG), gather_pad_lds(), stream, a);
         return hipGetLastError();
     }
     if (interp == kNearest)

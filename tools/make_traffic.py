@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the committed rocprofv3 summaries (tools/prof.sh output copied to profiles/).
+HBM bytes per launch = FETCH_SIZE (KiB) x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB) x 1024."""
+import json
+import os
+import re
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = {}
+for tag in ("u8_linear", "f32_linear", "u8_nearest"):
+    path = os.path.join(root, "profiles", "%s_%s_rocprofv3_summary.txt" % (rnd, tag))
+    txt = open(path).read()
+    fetch = float(re.search(r"FETCH_SIZE\s+([\d.]+)", txt).group(1))
+    write = float(re.search(r"WRITE_SIZE\s+([\d.]+)", txt).group(1))
+    avg = float(re.search(r"warp_\w+<.*?avg\s+([\d.]+) ns", txt).group(1))
+    out[tag] = {"hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "fetch_size_kib_raw": fetch, "write_size_kib": write,
+                "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)", "kernel_avg_ns_profiled": avg,
+                "source": os.path.relpath(path, root)}
+with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps(out, indent=1))
