@@ -1,0 +1,96 @@
+"""Parity of the row-classified path of warp_gather (destination tiles a whole number of 64-px evaluation blocks
+wide: 256 px for uint8, 128 px for float32, at least 16 rows) with the CPU oracle: every row class (FAST / OUT /
+EDGE / SLOW), every channel count, border values, rounding ties, W sign changes, degenerate sources.
+Bit-exact for every dtype (the float kernel keeps the oracle's operation order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_oracle as co
+from tests import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def W():
+    from bev_amd import warp
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return warp
+
+
+def run_gpu(W, src_np, M, dsize, interp, **kw):
+    out = W.warp_perspective(torch.from_numpy(np.ascontiguousarray(src_np)).cuda(), M, dsize, flags=interp, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def both(W, src, M, dsize, interp, **kw):
+    np.testing.assert_array_equal(run_gpu(W, src, M, dsize, interp, **kw), co.warp_perspective(src, M, dsize, interp, **kw))
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_channels_all_row_classes(W, c, dtype, interp):
+    """Brno-style BEV: a third of the rows FAST, a third OUT, the frame's edge crossing the rest."""
+    M = wl.synth_brno_H(640, 360, 512, 80)
+    src = wl.frame(5, 360, 640, dtype, c)
+    both(W, src, M, (512, 80), interp)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_border_values(W, dtype, interp):
+    """Non-zero border: OUT rows are filled for uint8 / nearest; float bilinear blends four border taps per pixel."""
+    M = wl.synth_brno_H(640, 360, 512, 64)
+    src = wl.frame(6, 360, 640, dtype)
+    bv = [7, 200, 33] if dtype == np.uint8 else [0.3, 0.55, 0.7]
+    both(W, src, M, (512, 64), interp, border_value=bv)
+    both(W, src, M, (512, 64), interp, border_value=bv[0])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_rounding_ties_on_fast_rows(W, dtype):
+    """Identity, integer and k/64-px shifts, x2 zoom: every coordinate sits on (or next to) a rounding boundary."""
+    src = wl.frame(7, 200, 700, dtype)
+    for M in (np.eye(3), np.array([[1, 0, -17.0], [0, 1, -9.0], [0, 0, 1]]), np.array([[1, 0, -3.515625], [0, 1, -2.984375], [0, 0, 1]]),
+              np.array([[2.0, 0, -40.0], [0, 2.0, -30.0], [0, 0, 1]]), np.array([[0.5, 0, -1.0], [0, 0.5, -1.0], [0, 0, 1]])):
+        for interp in (0, 1):
+            both(W, src, M, (512, 48), interp)
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+def test_w_sign_change_and_far_coordinates(W, interp):
+    """Horizon inside the destination (W changes sign along rows and between rows), coordinates beyond 2^26 px
+    next to it, and a destination that sees nothing of the frame."""
+    src = wl.frame(8, 120, 160, np.uint8)
+    M = np.array([[1.0, 0.2, 3.0], [0.1, 1.0, 2.0], [0.004, 0.02, -1.5]])
+    both(W, src, M, (512, 96), interp)
+    M2 = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [1.0 / 300.0, 0.0, -1.0]])  # W = 0 along a column
+    both(W, src, M2, (512, 32), interp)
+    T = np.array([[1, 0, 1e7], [0, 1, 0], [0, 0, 1.0]])
+    assert not run_gpu(W, src, T, (512, 32), interp).any()
+    both(W, src.astype(np.float32) / 255, M, (256, 64), interp)
+
+
+@pytest.mark.parametrize("sw,sh", [(1, 1), (2, 2), (3, 2), (5, 1), (2, 40)])
+def test_tiny_sources(W, sw, sh):
+    """Sources smaller than the unguarded load window: no row may take the FAST class."""
+    for dtype in (np.uint8, np.float32):
+        src = wl.frame(9, sh, sw, dtype)
+        M = np.array([[200.0 / max(sw, 2), 3.0, 20.0], [1.0, 12.0 / max(sh, 2), 4.0], [0, 0, 1.0]])
+        for interp in (0, 1):
+            both(W, src, M, (256, 32), interp)
+
+
+def test_padded_rows_batch_and_per_frame_matrices(W):
+    """Row-padded source views, several frames, one matrix each, ragged last tile row (dst_h not a multiple of 16)."""
+    B, sw, sh, dw, dh = 3, 600, 300, 512, 41
+    base = wl.synth_brno_H(1920, 1080, dw, dh) @ np.diag([1920 / sw, 1080 / sh, 1.0])
+    Ms = np.stack([wl.jitter_H(base, i, px=7.0) for i in range(B)])
+    big = torch.from_numpy(np.stack([wl.frame(10 + i, sh, sw + 24, np.uint8) for i in range(B)])).cuda()
+    view = big[:, :, 12:12 + sw]
+    got = W.warp_perspective(view, Ms, (dw, dh)).cpu().numpy()
+    for i in range(B):
+        np.testing.assert_array_equal(got[i], co.warp_perspective(np.ascontiguousarray(view[i].cpu().numpy()), Ms[i], (dw, dh)))
