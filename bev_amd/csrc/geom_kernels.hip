@@ -5,7 +5,8 @@
 // f64 2-D point); each lane handles two points = one 16-byte load and one 16-byte store (f32),
 // or one point = 16 B (f64).
 // rbox_iou: N x M IoU of rotated rectangles (reference bev/tracker/rbox_tracker.py:87-92 -> d3d),
-// one lane per pair, convex clipping fully in registers.  Latency/ALU bound (output ~1 MB).
+// one lane per pair: circumscribed-circle rejection first, convex clipping for the pairs that may touch.
+// Latency/ALU bound (output ~1 MB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -70,61 +71,82 @@ __device__ __forceinline__ Quad corners_of(double cx, double cy, double w, doubl
     return q;
 }
 
-// Sutherland-Hodgman: clip polygon (<= 8 vertices) against the 4 half-planes of quad B.
-__device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B) {
-    double px[8], py[8], qx[8], qy[8];
-    int n = 4;
+// Sutherland-Hodgman: clip polygon (<= 8 vertices) against the 4 half-planes of quad B.  The two vertex lists
+// ping-pong in LDS (vertex-major, one column per thread: dynamic indexing without scratch memory); the signed
+// distance of a vertex is computed once and carried to the next edge test.  Same expressions, same order as
+// oracle/warp_oracle.c.
+constexpr int kIouThreads = 256;
+__device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B, double* __restrict__ lds, int tid) {
+    auto P = [&](int buf, int xy, int k) -> double& { return lds[((buf * 2 + xy) * 8 + k) * kIouThreads + tid]; };
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        px[i] = A.x[i];
-        py[i] = A.y[i];
+        P(0, 0, i) = A.x[i];
+        P(0, 1, i) = A.y[i];
     }
+    int cur = 0, n = 4;
     for (int e = 0; e < 4 && n > 0; e++) {
         const int e1 = (e + 1) & 3;
-        const double ex = B.x[e1] - B.x[e], ey = B.y[e1] - B.y[e];
+        const double bx = B.x[e], by = B.y[e];
+        const double ex = B.x[e1] - bx, ey = B.y[e1] - by;
         int m = 0;
+        double xi = P(cur, 0, 0), yi = P(cur, 1, 0);
+        double di = ex * (yi - by) - ey * (xi - bx);
         for (int i = 0; i < n; i++) {
             const int j = (i + 1 == n) ? 0 : i + 1;
-            const double di = ex * (py[i] - B.y[e]) - ey * (px[i] - B.x[e]);
-            const double dj = ex * (py[j] - B.y[e]) - ey * (px[j] - B.x[e]);
+            const double xj = P(cur, 0, j), yj = P(cur, 1, j);
+            const double dj = ex * (yj - by) - ey * (xj - bx);
             if (di >= 0) {
-                qx[m] = px[i];
-                qy[m] = py[i];
+                P(cur ^ 1, 0, m) = xi;
+                P(cur ^ 1, 1, m) = yi;
                 m++;
             }
             if ((di >= 0) != (dj >= 0)) {
                 const double t = di / (di - dj);
-                qx[m] = px[i] + t * (px[j] - px[i]);
-                qy[m] = py[i] + t * (py[j] - py[i]);
+                P(cur ^ 1, 0, m) = xi + t * (xj - xi);
+                P(cur ^ 1, 1, m) = yi + t * (yj - yi);
                 m++;
             }
+            xi = xj, yi = yj, di = dj;
         }
         n = m;
-        for (int i = 0; i < n; i++) {
-            px[i] = qx[i];
-            py[i] = qy[i];
-        }
+        cur ^= 1;
     }
     if (n < 3) return 0.0;
     double a = 0.0;
+    double xi = P(cur, 0, 0), yi = P(cur, 1, 0);
     for (int i = 0; i < n; i++) {
         const int j = (i + 1 == n) ? 0 : i + 1;
-        a += px[i] * py[j] - px[j] * py[i];
+        const double xj = P(cur, 0, j), yj = P(cur, 1, j);
+        a += xi * yj - xj * yi;
+        xi = xj, yi = yj;
     }
     return fabs(0.5 * a);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
+__global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
+    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];  // 64 KiB: two vertex lists per thread
     const int j = blockIdx.x * blockDim.x + threadIdx.x;  // column (box of b) -> coalesced stores
     const int i = blockIdx.y;
     if (j >= nb) return;
     const T* pa = a + (int64_t)i * sa;
     const T* pb = b + (int64_t)j * sb;
+    {   // boxes whose circumscribed circles are apart cannot intersect: the clip below would return exactly 0 for
+        // them.  In a tracker step almost every pair ends here, before any sin / cos or clipping (the 1e-4 margin
+        // keeps near-touching pairs on the exact path; NaNs fall through to it as well).
+        const double dx = (double)pa[0] - (double)pb[0], dy = (double)pa[1] - (double)pb[1];
+        const double ra2 = (double)pa[2] * (double)pa[2] + (double)pa[3] * (double)pa[3];
+        const double rb2 = (double)pb[2] * (double)pb[2] + (double)pb[3] * (double)pb[3];
+        const double rs = 0.5 * (sqrt(ra2) + sqrt(rb2));
+        if (dx * dx + dy * dy > rs * rs * 1.0001 && fabs((double)pa[2] * (double)pa[3]) + fabs((double)pb[2] * (double)pb[3]) > 0) {
+            out[(int64_t)i * nb + j] = (T)0.0;
+            return;
+        }
+    }
     const Quad A = corners_of((double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]);
     const Quad B = corners_of((double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]);
-    const double inter = intersection_area(A, B);
+    const double inter = intersection_area(A, B, s_poly, (int)threadIdx.x);
     const double uni = fabs((double)pa[2] * (double)pa[3]) + fabs((double)pb[2] * (double)pb[3]) - inter;
     out[(int64_t)i * nb + j] = (T)(uni > 0 ? inter / uni : 0.0);
 }
