@@ -820,7 +820,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (register budget: 4 waves per SIMD -- what the FAST row loop needs without spilling; the rare row
 // classes may spill)
 template <typename T, int C, int INTERP>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? 4 : BEVWARP_F32_WAVES))) void warp_gather(const WarpArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? (C == 3 && INTERP == kLinear ? 3 : 4) : BEVWARP_F32_WAVES))) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int GX = kGatherLX, GY = 64 / kGatherLX, GROWS = GY * (kWG / 64);  // lanes along x / y, rows per pass
     constexpr int TW = GX * PPL;
@@ -1007,12 +1007,22 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     // the same edge no pixel touches the frame (OUT: the border value).  When the frame's edge crosses the segment
     // (EDGE) the coordinates of the fast chain still hold and only the pixels next to the edge take guarded taps;
     // when W changes sign or is tiny, or coordinates pass 2^26 px (SLOW), the row takes the exact per-pixel chain.
-    if (GY == 1 && a.bw0 == 64 && any_fast && x0 + TW <= a.dst_w && a.dst_vec_ok) {
+    if (GY == 1 && a.bw0 == 64 && any_fast && (int64_t)a.src_w * PBs >= 32 && x0 + TW <= a.dst_w && a.dst_vec_ok) {
         // lane-INTERLEAVED ownership: pixel j of lane l is x0 + 64 j + l, so one load instruction covers 64 consecutive
         // destination pixels whose taps sit in a handful of cache lines.  Pixel j lies in evaluation block j of the
         // tile and x1 = l for every j.  Results are transposed to consecutive-per-lane order through a wave-private
         // LDS row before the (contiguous) store.
         enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
+        // 8-bit RGB bilinear: a tap pair (6 bytes at any byte address) is fetched as the ALIGNED 12-byte window around
+        // it and funnel-shifted into place.  The texture path turns byte-unaligned 8-byte gathers that miss L1 into
+        // data at ~50 cycles per wave instruction and 4-byte-aligned 12-byte ones at ~18 (tools/ubench_stream.hip).
+        constexpr bool kAligned = sizeof(T) == 1 && C == 3 && INTERP == kLinear;
+        constexpr int WINB = kAligned ? 12 : LOADB;  // bytes a FAST row loads per tap row
+        constexpr int kInMargin = kAligned ? 2 : 1;   // FAST: both ends inside by this many pixels (the aligned window
+                                                      // starts up to 3 bytes early: never before its row)
+        const int sxw_lim = (int)(((int64_t)a.src_w * PBs - WINB) / PBs);  // largest sx with sx*PBs + WINB <= w*PBs
+        const uint32_t fa = kAligned ? (uint32_t)(reinterpret_cast<uintptr_t>(frame) & 3u) : 0u;
+        const uint8_t* frame_al = frame - fa;  // 4-byte aligned (frames need not be)
         // Row terms.  The reference's chain is X0 = (M0*bx + M1*y) + M2, X = X0 + M0*(x - bx) per evaluation block;
         // the fast chain below only has to land within 2^-20 of a coordinate unit of it (anything closer than
         // 2^-19 to a rounding boundary is redone exactly), which leaves ~12 bits of slack over float64 rounding.
@@ -1099,8 +1109,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             constexpr uint32_t kCoordBias = INTERP == kLinear ? (1u << 26) : (1u << 31);
             const int sxa = (int)((lane_u32(RX[0], 0) >> SH) - kCoordBias), sya = (int)((lane_u32(RY[0], 0) >> SH) - kCoordBias);
             const int sxb = (int)((lane_u32(RX[PPL - 1], 63) >> SH) - kCoordBias), syb = (int)((lane_u32(RY[PPL - 1], 63) >> SH) - kCoordBias);
-            const bool in = (uint32_t)(sxa - 1) <= (uint32_t)(sx_lim - 2) && (uint32_t)(sxb - 1) <= (uint32_t)(sx_lim - 2) &&
-                            (uint32_t)(sya - 1) <= (uint32_t)(sy_lim - 2) && (uint32_t)(syb - 1) <= (uint32_t)(sy_lim - 2) && sx_lim >= 2 && sy_lim >= 2;
+            constexpr int kM = kInMargin;
+            const bool in = (uint32_t)(sxa - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(sxb - kM) <= (uint32_t)(sxw_lim - 2 * kM) &&
+                            (uint32_t)(sya - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syb - kM) <= (uint32_t)(sy_lim - 2 * kM) &&
+                            sxw_lim >= 2 * kM && sy_lim >= 2 * kM;
             const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
             // kEdge: the coordinates are good, taps need guards
             const int cls = !(e_bad == 0 && w_ok) ? kSlow : (in ? kFast : ((out && fill_ok) ? kOut : kEdge));
@@ -1122,19 +1134,29 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         };
         const uint8_t* frame_r1 = frame + rs32;
         // (rows that are not FAST load from offset 0: the row loop keeps one shape for every class)
-        auto issue_s = [&](int cls, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) {
+        auto issue_s = [&](int cls, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<WINB> (&t0)[PPL], Bytes<WINB> (&t1)[PPL],
+                           uint32_t (&S0)[PPL], uint32_t (&S1)[PPL]) {
             // FAST rows sample inside the frame: 0 <= sx, sy < 2^15, so 16-bit fields drop the 2^31 bias and 24-bit
             // multiplies build the byte offset (the host guarantees row stride < 2^24 and frames < 2 GiB)
             const uint32_t rs_eff = cls == kFast ? rs32 : 0u, pb_eff = cls == kFast ? (uint32_t)PBs : 0u;
+            const uint32_t o_base = kAligned ? (cls == kFast ? fa : 4u) : 0u;  // (4: a dummy window inside the frame)
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t sx = __builtin_amdgcn_ubfe(RX[j], SH, 16), sy = __builtin_amdgcn_ubfe(RY[j], SH, 16);
-                const uint32_t off = __umul24(sy, rs_eff) + __umul24(sx, pb_eff);
+                const uint32_t off = __umul24(sy, rs_eff) + (__umul24(sx, pb_eff) + o_base);
 #if defined(BEVWARP_ABLATE) && (BEVWARP_ABLATE & 1)  // diagnostic builds only: no tap loads
-                for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
+                for (int k = 0; k < WINB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
+                S0[j] = S1[j] = off;
 #else
-                __builtin_memcpy(&t0[j], frame + off, LOADB);
-                if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame_r1 + off, LOADB);  // second tap row: same offset, base + row stride
+                if constexpr (kAligned) {
+                    const uint32_t off1 = off + rs_eff;
+                    __builtin_memcpy(&t0[j], frame_al + (off & ~3u), WINB);
+                    __builtin_memcpy(&t1[j], frame_al + (off1 & ~3u), WINB);
+                    S0[j] = off << 3, S1[j] = off1 << 3;  // funnel-shift amounts (v_alignbit reads bits 4:0)
+                } else {
+                    __builtin_memcpy(&t0[j], frame + off, LOADB);
+                    if (INTERP == kLinear) __builtin_memcpy(&t1[j], frame_r1 + off, LOADB);  // second tap row: same offset, base + row stride
+                }
 #endif
             }
         };
@@ -1154,8 +1176,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             }
             asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
         };
-        auto finish_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<LOADB> (&t0)[PPL],
-                            const Bytes<LOADB> (&t1)[PPL]) {
+        auto finish_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], const Bytes<WINB> (&t0)[PPL],
+                            const Bytes<WINB> (&t1)[PPL], const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL]) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 const uint32_t fx = RX[j] & 31u, fy = RY[j] & 31u;
@@ -1167,6 +1189,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                     } else if constexpr (C == 3) {
                         px = (t0[j].w[0] ^ t0[j].w[1] ^ t1[j].w[0] ^ t1[j].w[1]) + fx + fy;
 #endif
+                    } else if constexpr (kAligned) {
+                        const uint32_t a0 = __builtin_amdgcn_alignbit(t0[j].w[1], t0[j].w[0], S0[j]), a1 = __builtin_amdgcn_alignbit(t0[j].w[2], t0[j].w[1], S0[j]);
+                        const uint32_t b0 = __builtin_amdgcn_alignbit(t1[j].w[1], t1[j].w[0], S1[j]), b1 = __builtin_amdgcn_alignbit(t1[j].w[2], t1[j].w[1], S1[j]);
+                        px = blend_u8_rgb_window(a0, a1, b0, b1, fx, fy);
                     } else if constexpr (C == 3) {
                         px = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
                     } else if constexpr (C == 4) {
@@ -1225,7 +1251,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         };
         // EDGE row: unguarded window loads + the fast blend for the pixels whose taps are inside, the border value for
         // those whose taps are all outside, guarded taps for the few in between
-        auto edge_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL], Bytes<LOADB> (&t1)[PPL]) __attribute__((always_inline)) {
+        auto edge_s = [&](const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<WINB> (&t0)[PPL], Bytes<WINB> (&t1)[PPL]) __attribute__((always_inline)) {
             int X[PPL], Y[PPL];  // (t0, t1: the pipeline's tap registers, idle for a row that is not FAST)
             bool inb[PPL];
 #pragma unroll
@@ -1281,10 +1307,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 }
             }
         };
-        auto finish_any = [&](int cls, int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<LOADB> (&t0)[PPL],
-                              Bytes<LOADB> (&t1)[PPL], uint4 (&out)[NQ]) {
+        auto finish_any = [&](int cls, int y, const uint32_t (&RX)[PPL], const uint32_t (&RY)[PPL], Bytes<WINB> (&t0)[PPL],
+                              Bytes<WINB> (&t1)[PPL], const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], uint4 (&out)[NQ]) {
             if (__builtin_expect(cls == kFast, 1)) {
-                finish_s(RX, RY, t0, t1);
+                finish_s(RX, RY, t0, t1, S0, S1);
             } else {
                 if (cls == kOut)
                     fill_s();
@@ -1330,16 +1356,17 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         int yf = y0 + wave;
         if (yf > y_last) return;
         uint32_t RXc[PPL], RYc[PPL], RXn[PPL], RYn[PPL];
-        Bytes<LOADB> u0[PPL], u1[PPL];
+        Bytes<WINB> u0[PPL], u1[PPL];
+        uint32_t S0[PPL], S1[PPL];
         uint4 out[NQ];
         int cls_c = coords_s(yf, RXc, RYc), cls_n = kSlow;
-        issue_s(cls_c, RXc, RYc, u0, u1);
+        issue_s(cls_c, RXc, RYc, u0, u1, S0, S1);
         // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt
         // retires in issue order, so a store issued before a row's loads would have to reach L2 before that row's
         // taps can be used; issued after them it has a whole iteration to complete.
         bool more = yf + GROWS <= y_last;
         if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);
-        finish_any(cls_c, yf, RXc, RYc, u0, u1, out);
+        finish_any(cls_c, yf, RXc, RYc, u0, u1, S0, S1, out);
         while (more) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -1347,12 +1374,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 RYc[j] = RYn[j];
             }
             cls_c = cls_n;
-            issue_s(cls_c, RXc, RYc, u0, u1);  // row yf + GROWS
+            issue_s(cls_c, RXc, RYc, u0, u1, S0, S1);  // row yf + GROWS
             store_s(yf, out);                  // row yf
             yf += GROWS;
             more = yf + GROWS <= y_last;
             if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);  // overlaps with the loads in flight
-            finish_any(cls_c, yf, RXc, RYc, u0, u1, out);
+            finish_any(cls_c, yf, RXc, RYc, u0, u1, S0, S1, out);
         }
         store_s(yf, out);
         return;
