@@ -136,7 +136,14 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     a.gather = (mode == 3 && tile_ok) ? 2 : ((lane_ok && (mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1)))) ? 1 : 0);
     const int tw = tile_width(dtype, a.gather);
     if (a.gather) {
-        const int dflt = band_rows(a.gather) * 4;  // four rows per lane
+        // rows per workgroup: 16 (four per wave) is the floor; 8-bit pixels are ALU-bound enough for the per-wave set-up
+        // to show, so they take 32-row tiles when the launch still has >= 4096 workgroups (16 per CU: footprints
+        // with large outside regions make workgroups uneven, and 64-row tiles lose more to the tail than they save)
+        int dflt = band_rows(a.gather) * 4;
+        if (a.gather == 1 && dtype == BEVWARP_U8) {
+            const int64_t per_row_of_tiles = (int64_t)batch * ((dst_w + tw - 1) / tw);
+            if (per_row_of_tiles * ((dst_h + 2 * dflt - 1) / (2 * dflt)) >= 4096) dflt *= 2;
+        }
         a.tile_h = env_int("BEVWARP_GATHER_TILE_H", dflt);
         if (a.tile_h < band_rows(a.gather) || a.tile_h > 1024 || a.tile_h % band_rows(a.gather)) a.tile_h = dflt;
     } else {
