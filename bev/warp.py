@@ -1,2 +1,2 @@
 from bev_amd.warp import (BORDER_CONSTANT, INTER_LINEAR, INTER_NEAREST, WARP_INVERSE_MAP, footprint,  # noqa: F401
-                          invert_homography, warp_perspective, warpPerspective)
+                          invert_homography, resize_matrix, warp_perspective, warp_perspective_resized, warpPerspective)

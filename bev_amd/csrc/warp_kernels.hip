@@ -1353,8 +1353,17 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             }
         };
         // rows of a tile are dealt to its waves round-robin: neighbouring rows share source lines and run at the same time
+#if defined(BEVWARP_ROWS_CONTIG)  // experiment: each wave takes a contiguous quarter of the tile's rows
+        constexpr int RSTEP = 1;
+        const int rpw = a.tile_h / (kWG / 64);
+        int yf = y0 + wave * rpw;
+        const int y_end = min(yf + rpw - 1, y_last);
+#else
+        constexpr int RSTEP = GROWS;
         int yf = y0 + wave;
-        if (yf > y_last) return;
+        const int y_end = y_last;
+#endif
+        if (yf > y_end) return;
         uint32_t RXc[PPL], RYc[PPL], RXn[PPL], RYn[PPL];
         Bytes<WINB> u0[PPL], u1[PPL];
         uint32_t S0[PPL], S1[PPL];
@@ -1364,8 +1373,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt
         // retires in issue order, so a store issued before a row's loads would have to reach L2 before that row's
         // taps can be used; issued after them it has a whole iteration to complete.
-        bool more = yf + GROWS <= y_last;
-        if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);
+        bool more = yf + RSTEP <= y_end;
+        if (more) cls_n = coords_s(yf + RSTEP, RXn, RYn);
         finish_any(cls_c, yf, RXc, RYc, u0, u1, S0, S1, out);
         while (more) {
 #pragma unroll
@@ -1376,9 +1385,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             cls_c = cls_n;
             issue_s(cls_c, RXc, RYc, u0, u1, S0, S1);  // row yf + GROWS
             store_s(yf, out);                  // row yf
-            yf += GROWS;
-            more = yf + GROWS <= y_last;
-            if (more) cls_n = coords_s(yf + GROWS, RXn, RYn);  // overlaps with the loads in flight
+            yf += RSTEP;
+            more = yf + RSTEP <= y_end;
+            if (more) cls_n = coords_s(yf + RSTEP, RXn, RYn);  // overlaps with the loads in flight
             finish_any(cls_c, yf, RXc, RYc, u0, u1, S0, S1, out);
         }
         store_s(yf, out);

@@ -146,3 +146,28 @@ def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORD
         dst[...] = res
         return dst
     return res
+
+
+def resize_matrix(src_wh, new_wh, align_corners=False):
+    """3x3 map from pixels of a (w, h) image to pixels of its resized (new_w, new_h) version, in the convention of
+    the reference's Calib.scale (bev/calib.py:142-198): x' = (x + 0.5) * r - 0.5 (align_corners=False, what
+    cv2.resize does) or x' = x * (new - 1) / (old - 1)."""
+    (w, h), (nw, nh) = src_wh, new_wh
+    if align_corners:
+        ru, rv = (nw - 1) / (w - 1), (nh - 1) / (h - 1)
+        return np.array([[ru, 0, 0], [0, rv, 0], [0, 0, 1.0]])
+    ru, rv = nw / w, nh / h
+    return np.array([[ru, 0, 0.5 * ru - 0.5], [0, rv, 0.5 * rv - 0.5], [0, 0, 1.0]])
+
+
+def warp_perspective_resized(src, M_resized, dsize, new_wh, align_corners=False, **kw):
+    """The "small" branch of vis_homo.py:73-78,90-91 -- cv2.resize(img, new_wh) followed by
+    cv2.warpPerspective(img_small, H_bev_img_small, dsize) -- with the resize folded into the homography: the
+    full-resolution frame is sampled once through M_resized @ resize_matrix(...), no intermediate image exists.
+    `M_resized` maps pixels of the RESIZED image to the destination (H_bev_img_small).  The result is the warp of the
+    full-resolution frame (sharper than the two-step path, which low-passes through the resize); it is bit-identical
+    to warp_perspective(src, M_resized @ S, dsize).  Keyword arguments as for warp_perspective."""
+    h, w = (src.shape[-3], src.shape[-2]) if src.dim() >= 3 else src.shape
+    S = resize_matrix((w, h), new_wh, align_corners)
+    return warp_perspective(src, np.asarray(M_resized, dtype=np.float64) @ S, dsize, **kw)
+

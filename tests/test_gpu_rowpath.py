@@ -94,3 +94,27 @@ def test_padded_rows_batch_and_per_frame_matrices(W):
     got = W.warp_perspective(view, Ms, (dw, dh)).cpu().numpy()
     for i in range(B):
         np.testing.assert_array_equal(got[i], co.warp_perspective(np.ascontiguousarray(view[i].cpu().numpy()), Ms[i], (dw, dh)))
+
+
+def test_fused_resize_warp_small_branch(W):
+    """SURVEY.md 8(f1), vis_homo.py:73-78,90-91: the resize folded into the homography.  Bit-identical to the oracle
+    warp through M_small @ S; close to the two-step path (resize, then warp) on a smooth frame."""
+    import bev
+    from bev_amd.homo import compose_H_bev_img
+    calib = bev.Calib(vp1=np.array([1200.0, -300.0]), vp2=np.array([-2500.0, -150.0]), pp=np.array([959.5, 539.5]), height=8, u_size=1920, v_size=1080)
+    center = calib.gen_center_in_world()
+    bspec = bev.BEVWorldSpec(u_size=512, v_size=256, u_axis="y", v_axis="-x", x_size=64, y_size=64, x_min=center[0] - 20, y_min=center[1] - 32)
+    small = calib.scale(align_corners=False, new_u=852, new_v=480)
+    M_small = compose_H_bev_img(bspec.gen_H_world_bev(), small.gen_H_world_img())
+    yy, xx = np.mgrid[0:1080, 0:1920]
+    img = np.stack([128 + 100 * np.sin(xx / 97.0) * np.cos(yy / 71.0), xx * 255.0 / 1919, yy * 255.0 / 1079], axis=2).astype(np.uint8)
+    t = torch.from_numpy(img).cuda()
+    got = W.warp_perspective_resized(t, M_small, (512, 256), (852, 480)).cpu().numpy()
+    S = W.resize_matrix((1920, 1080), (852, 480))
+    np.testing.assert_array_equal(got, co.warp_perspective(img, M_small @ S, (512, 256), 1))
+    # two-step path: bilinear resize with half-pixel centres (what cv2.resize computes, up to its fixed-point rounding)
+    sm = torch.nn.functional.interpolate(t.permute(2, 0, 1)[None].float(), size=(480, 852), mode="bilinear", align_corners=False)
+    sm = sm[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
+    two = W.warp_perspective(sm, M_small, (512, 256)).cpu().numpy()
+    inside = (two.sum(axis=2) > 0) & (got.sum(axis=2) > 0)
+    assert np.abs(got.astype(int) - two.astype(int))[inside].mean() < 1.5

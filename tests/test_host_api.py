@@ -346,3 +346,25 @@ def test_rbox_torch(golden):
         aa = rbox_torch.xywhr2xyxy(tb, mode, external_aa=True)
         assert aa.shape == (len(boxes), 4)
     close(rbox_torch.xy82xyvec(torch.from_numpy(rbox.xywhr2xyxy(boxes, "bev"))).numpy(), g["xy82xyvec_torch"])
+
+
+def test_resize_matrix_matches_calib_scale():
+    """Folding cv2.resize into the homography: resize_matrix follows the pixel conventions of the
+    reference's Calib.scale (bev/calib.py:142-198; vis_homo.py:73-78).  For an aspect-preserving resize the scaled
+    calibration is exactly the original one seen through S: H_world_img_small @ S == H_world_img up to scale (for
+    852x480 the reference's vanishing-point model is only approximately consistent, by ~1e-3)."""
+    import bev
+    from bev.warp import resize_matrix
+    S = resize_matrix((1920, 1080), (852, 480), False)
+    np.testing.assert_allclose(S @ [-0.5, -0.5, 1], [-0.5, -0.5, 1], atol=1e-12)          # outer pixel edges map to
+    np.testing.assert_allclose(S @ [1919.5, 1079.5, 1], [851.5, 479.5, 1], atol=1e-9)     # outer pixel edges
+    S = resize_matrix((1920, 1080), (852, 480), True)
+    np.testing.assert_allclose(S @ [1919, 1079, 1], [851, 479, 1], atol=1e-9)             # corner centres to corner centres
+    calib = bev.Calib(vp1=np.array([1200.0, -300.0]), vp2=np.array([-2500.0, -150.0]), pp=np.array([959.5, 539.5]), height=8, u_size=1920, v_size=1080)
+    H = calib.gen_H_world_img()
+    for align in (False, True):
+        small = calib.scale(align_corners=align, new_u=960, new_v=540)
+        Hs = small.gen_H_world_img() @ resize_matrix((1920, 1080), (960, 540), align)
+        if align:  # (1919/959 != 1079/539: not aspect-preserving in this convention)
+            continue
+        np.testing.assert_allclose(Hs / Hs[2, 2], H / H[2, 2], rtol=1e-9, atol=1e-9)
