@@ -107,8 +107,9 @@ def load_traffic(dtype, interp, args):
 class Workload:
     """One dtype / interpolation variant of configs[1] resident on one GPU."""
 
-    def __init__(self, args, dtype, interp_name, rank, dev):
+    def __init__(self, args, dtype, interp_name, rank, dev, planar=False):
         from bev_amd import warp
+        self.planar = planar  # uint8 in, normalised float32 channel planes out (bevwarp_warp_planar, SURVEY.md 8(f2))
         from tests import workloads as wl
         self.warp, self.dtype, self.interp_name, self.args = warp, dtype, interp_name, args
         self.B = B = args.batch
@@ -121,7 +122,8 @@ class Workload:
         base = (wl.keystone_H if args.homography == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh)
         gidx = [rank * B + i for i in range(B)]  # global frame indices of this rank
         self.Ms = np.stack([wl.jitter_H(base, g) for g in gidx])
-        self.set_bytes = B * (sh * sw + dh * dw) * C * esz
+        out_esz = 4 if planar else esz
+        self.set_bytes = B * (sh * sw * esz + dh * dw * out_esz) * C
         self.nsets = args.sets or max(2, int(np.ceil(1.1e9 / self.set_bytes)))
         self.frames_np = [wl.frame(g, sh, sw, ndtype) for g in gidx[:min(B, 8)]]
         self.srcs, self.dsts = [], []
@@ -135,15 +137,18 @@ class Workload:
                 else:  # other sets: same statistics, different bytes (cheap on-device generation)
                     t[i] = self.srcs[0][(i + s) % B].flip(0) if s % 2 else self.srcs[0][(i + s) % B].flip(1)
             self.srcs.append(t)
-            self.dsts.append(torch.empty((B, dh, dw, C), dtype=tdtype, device=dev))
+            self.dsts.append(torch.empty((B, C, dh, dw), dtype=torch.float32, device=dev) if planar else torch.empty((B, dh, dw, C), dtype=tdtype, device=dev))
         self.minv = warp.device_inverse(self.Ms, dev)
         counts, touched = warp.footprint((sh, sw), self.Ms, (dw, dh), flags=self.interp, device=dev)
         self.footprint_px = int(counts.sum().item())
         del touched
-        self.algo_bytes = B * dh * dw * C * esz + self.footprint_px * C * esz
+        self.algo_bytes = B * dh * dw * C * out_esz + self.footprint_px * C * esz
 
     def step(self, i):
         k = i % self.nsets
+        if self.planar:
+            self.warp.warp_to_planar(self.srcs[k], None, (self.dw, self.dh), flags=self.interp, out=self.dsts[k], M_inv_device=self.minv)
+            return
         self.warp.warp_perspective(self.srcs[k], None, (self.dw, self.dh), flags=self.interp, out=self.dsts[k], M_inv_device=self.minv)
 
     def run(self, steps, warmup, barrier):
@@ -165,8 +170,8 @@ class Workload:
         kernel_s = float(launch_ms.mean()) / 1e3
         achieved = self.algo_bytes / kernel_s / 1e9
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(self.dtype, self.interp_name, self.args),
-                "kernel": "warp_gather<%s,3,%s>" % ("uint8" if self.esz == 1 else "float", self.interp_name),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if self.planar else load_traffic(self.dtype, self.interp_name, self.args),
+                "kernel": "warp_gather<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
                 "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
                 "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
                 "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
@@ -216,13 +221,13 @@ def main():
 
     if world == 1 and not args.no_variants:
         variants = []
-        for dt, ip in (("u8", "linear"), ("u8", "nearest"), ("f32", "linear")):
-            if (dt, ip) == (args.dtype, args.interp):
+        for dt, ip, planar in (("u8", "linear", False), ("u8", "nearest", False), ("f32", "linear", False), ("u8", "linear", True)):
+            if (dt, ip) == (args.dtype, args.interp) and not planar:
                 continue
-            w = Workload(args, dt, ip, rank, dev)
+            w = Workload(args, dt, ip, rank, dev, planar=planar)
             el, lm = w.run(max(20, args.steps // 2), max(5, args.warmup // 2), shard.barrier)
             n = max(20, args.steps // 2)
-            variants.append({"dtype": dt, "interp": ip, "value": round(w.B * w.dw * w.dh * n / 1e6 / el, 1), "unit": "Mpix/s",
+            variants.append({"dtype": dt if not planar else "u8 -> f32 planar", "interp": ip, "value": round(w.B * w.dw * w.dh * n / 1e6 / el, 1), "unit": "Mpix/s",
                              "ms_per_step": round(el / n * 1e3, 4), "roofline": w.roofline(lm)})
             del w
             torch.cuda.empty_cache()

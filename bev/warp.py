@@ -1,2 +1,3 @@
 from bev_amd.warp import (BORDER_CONSTANT, INTER_LINEAR, INTER_NEAREST, WARP_INVERSE_MAP, footprint,  # noqa: F401
-                          invert_homography, resize_matrix, warp_perspective, warp_perspective_resized, warpPerspective)
+                          invert_homography, resize_matrix, warp_perspective, warp_perspective_resized, warp_to_planar,
+                          warpPerspective)

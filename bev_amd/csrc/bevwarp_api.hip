@@ -88,9 +88,17 @@ int bevwarp_invert_homography(const double* S, double* D, int n) {
     return BEVWARP_OK;
 }
 
-int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
-                 int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv,
-                 int m_count, int dtype, int interp, const double* border_value, void* stream) {
+}  // extern "C"
+
+namespace {
+struct PlanarOut {  // bevwarp_warp_planar: float32 channel planes instead of interleaved pixels of the source type
+    int64_t plane_stride;
+    const double *scale, *bias;
+};
+
+int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+              int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv,
+              int m_count, int dtype, int interp, const double* border_value, void* stream, const PlanarOut* po) {
     using namespace bevwarp;
     if (!src || !dst || !M_inv) return BEVWARP_ERR_BAD_ARG;
     if (batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
@@ -100,11 +108,18 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     if (m_count != 1 && m_count != batch) return BEVWARP_ERR_BAD_ARG;
     const int esz = dtype == BEVWARP_U8 ? 1 : 4;
     const int64_t pix = (int64_t)channels * esz;
-    if (src_row_stride < src_w * pix || dst_row_stride < dst_w * pix) return BEVWARP_ERR_BAD_ARG;
-    if (batch > 1 && (src_frame_stride < src_h * src_row_stride || dst_frame_stride < dst_h * dst_row_stride)) return BEVWARP_ERR_BAD_ARG;
-    if ((src_row_stride % esz) || (dst_row_stride % esz) || (src_frame_stride % esz) || (dst_frame_stride % esz) ||
-        ((uintptr_t)src % esz) || ((uintptr_t)dst % esz))
-        return BEVWARP_ERR_BAD_ARG;
+    if (src_row_stride < src_w * pix) return BEVWARP_ERR_BAD_ARG;
+    if (batch > 1 && src_frame_stride < src_h * src_row_stride) return BEVWARP_ERR_BAD_ARG;
+    if ((src_row_stride % esz) || (src_frame_stride % esz) || ((uintptr_t)src % esz)) return BEVWARP_ERR_BAD_ARG;
+    if (po) {  // destination: `channels` float32 planes per frame
+        if (dst_row_stride < (int64_t)dst_w * 4 || po->plane_stride < dst_h * dst_row_stride) return BEVWARP_ERR_BAD_ARG;
+        if (batch > 1 && dst_frame_stride < channels * po->plane_stride) return BEVWARP_ERR_BAD_ARG;
+        if ((dst_row_stride % 4) || (po->plane_stride % 4) || (dst_frame_stride % 4) || ((uintptr_t)dst % 4)) return BEVWARP_ERR_BAD_ARG;
+    } else {
+        if (dst_row_stride < dst_w * pix) return BEVWARP_ERR_BAD_ARG;
+        if (batch > 1 && dst_frame_stride < dst_h * dst_row_stride) return BEVWARP_ERR_BAD_ARG;
+        if ((dst_row_stride % esz) || (dst_frame_stride % esz) || ((uintptr_t)dst % esz)) return BEVWARP_ERR_BAD_ARG;
+    }
     if (src_w > 32767 || src_h > 32767) return BEVWARP_ERR_TOO_LARGE;
     if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31) || src_row_stride >= (1 << 24)) return BEVWARP_ERR_TOO_LARGE;  // (kernels use 24-bit multiplies)
     if (batch == 0) return BEVWARP_OK;
@@ -134,6 +149,10 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     const bool lane_ok = (a.bw0 % pixels_per_lane_of(dtype) == 0) || (a.bw0 >= dst_w);
     const bool tile_ok = (a.bw0 % tile_width(dtype, 2) == 0) || (a.bw0 >= dst_w);
     a.gather = (mode == 3 && tile_ok) ? 2 : ((lane_ok && (mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1)))) ? 1 : 0);
+    if (po) {  // planar output lives in warp_gather only
+        if (!lane_ok) return BEVWARP_ERR_UNSUPPORTED;
+        a.gather = 1;
+    }
     const int tw = tile_width(dtype, a.gather);
     if (a.gather) {
         // rows per workgroup: 16 (four per wave) is the floor; 8-bit pixels are ALU-bound enough for the per-wave set-up
@@ -181,8 +200,19 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     const int src_align = (u8x3 && a.gather != 2) ? 4 : 16;
     a.src_vec_ok = (src_w % 4 == 0 || a.gather == 2) && ((uintptr_t)src % src_align == 0) && (src_row_stride % src_align == 0) &&
                    (src_frame_stride % src_align == 0) && a.lds_bytes > 0 && !env_int("BEVWARP_NO_LDS", 0);
-    const int dst_align = u8x3 ? 4 : 16;
+    const int dst_align = (u8x3 && !po) ? 4 : 16;
     a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);
+    if (po) {
+        a.planar = 1;
+        a.dst_ps = po->plane_stride;
+        a.dst_vec_ok = a.dst_vec_ok && (po->plane_stride % 16 == 0);
+        for (int k = 0; k < 4; k++) {
+            const double sc = (po->scale && k < channels) ? po->scale[k] : 1.0, bi = (po->bias && k < channels) ? po->bias[k] : 0.0;
+            if (!isfinite(sc) || !isfinite(bi)) return BEVWARP_ERR_NOT_FINITE;
+            a.pscale[k] = (float)sc;
+            a.pbias[k] = (float)bi;
+        }
+    }
     for (int k = 0; k < 4; k++) {
         const double b = (border_value && k < channels) ? border_value[k] : 0.0;
         if (!isfinite(b)) return BEVWARP_ERR_NOT_FINITE;
@@ -192,6 +222,25 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
     }
     const hipError_t e = launch_warp(a, dtype, channels, interp, (hipStream_t)stream);
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+}  // namespace
+
+extern "C" {
+
+int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                 int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv,
+                 int m_count, int dtype, int interp, const double* border_value, void* stream) {
+    return warp_impl(src, dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride,
+                     M_inv, m_count, dtype, interp, border_value, stream, nullptr);
+}
+
+int bevwarp_warp_planar(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                        int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,
+                        int64_t dst_row_stride, const double* M_inv, int m_count, int interp, const double* border_value, const double* scale,
+                        const double* bias, void* stream) {
+    const PlanarOut po = {dst_plane_stride, scale, bias};
+    return warp_impl(src, dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride,
+                     M_inv, m_count, BEVWARP_U8, interp, border_value, stream, &po);
 }
 
 int bevwarp_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* M_inv, int m_count,

@@ -29,6 +29,10 @@ struct WarpArgs {
     int gather;                  // 1 = warp_gather (no LDS staging), 0 = warp_tiles
     float bval_f[4];
     uint8_t bval_u8[4];
+    // planar float output of 8-bit warps (bevwarp_warp_planar): dst[c][y][x] = float(pixel) * pscale[c] + pbias[c]
+    int planar;
+    int64_t dst_ps;              // bytes between channel planes
+    float pscale[4], pbias[4];
 };
 
 int tile_width(int dtype, int kernel);  // kernel: 0 = warp_tiles, 1 = warp_gather, 2 = warp_wave

@@ -360,6 +360,18 @@ __device__ __forceinline__ void stage_region(const WarpArgs& a, const uint8_t* _
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int C, int PPL>
 __device__ __forceinline__ void store_pixels(const WarpArgs& a, uint8_t* __restrict__ drow, int x, int nvalid, const Pixel<T, C>* v) {
+    if constexpr (sizeof(T) == 1) {
+        if (a.planar) {  // bevwarp_warp_planar, tiles outside the row path: scalar float stores into the channel planes
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                if (j >= nvalid) break;
+#pragma unroll
+                for (int k = 0; k < C; k++)
+                    reinterpret_cast<float*>(drow + k * a.dst_ps)[x + j] = (float)((v[j].packed >> (8 * k)) & 0xffu) * a.pscale[k] + a.pbias[k];
+            }
+            return;
+        }
+    }
     T* d = reinterpret_cast<T*>(drow) + (int64_t)x * C;
     if (nvalid == PPL && a.dst_vec_ok) {
         if constexpr (sizeof(T) == 1 && C == 3) {
@@ -1329,8 +1341,20 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             if ((y & 63) != 0 && out[0].x != 0x12345678u) return;
 #endif
             if constexpr (sizeof(T) == 1) {  // the lane's 4 pixels = 4 C contiguous bytes, one instruction
-                uint8_t* d = drow + lane * (PPL * C);
                 const uint32_t p0 = out[0].x, p1 = out[0].y, p2 = out[0].z, p3 = out[0].w;
+                if (a.planar) {  // float planes: one 16-byte store per channel (bevwarp_warp_planar)
+                    uint8_t* dp = dframe + (int64_t)y * a.dst_rs + (int64_t)(x0 + lane * PPL) * 4;
+#pragma unroll
+                    for (int k = 0; k < C; k++) {
+                        const float sc = a.pscale[k], bi = a.pbias[k];
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        f32x4 o = {(float)((p0 >> (8 * k)) & 0xffu) * sc + bi, (float)((p1 >> (8 * k)) & 0xffu) * sc + bi,
+                                   (float)((p2 >> (8 * k)) & 0xffu) * sc + bi, (float)((p3 >> (8 * k)) & 0xffu) * sc + bi};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dp + k * a.dst_ps));
+                    }
+                    return;
+                }
+                uint8_t* d = drow + lane * (PPL * C);
                 if constexpr (C == 1) {
                     __builtin_nontemporal_store(p0 | (p1 << 8) | (p2 << 16) | (p3 << 24), reinterpret_cast<uint32_t*>(d));
                 } else if constexpr (C == 2) {

@@ -114,6 +114,60 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     return d4
 
 
+def warp_to_planar(src, M, dsize, scale=1.0 / 255.0, bias=0.0, flags=INTER_LINEAR, border_value=None, out=None, M_inv_device=None):
+    """Warp uint8 frames and write them as normalised float32 channel planes in the same pass (the
+    layout a detector takes, `(B, C, v_size, u_size)`), without materialising the uint8 BEV frame:
+
+        out[b, c] = warp_perspective(src, M, dsize)[b, :, :, c].float() * scale[c] + bias[c]      (float32 mul, then add)
+
+    src (B, H, W, C) / (H, W, C) / (H, W) uint8 CUDA tensor; scale / bias scalars or per-channel sequences (e.g.
+    1 / (255 * std) and -mean / std); other arguments as warp_perspective.  Returns (B, C, h, w), or (C, h, w) for a
+    single frame.  Asynchronous on the current stream."""
+    if not isinstance(src, torch.Tensor) or not src.is_cuda or src.dtype != torch.uint8:
+        raise ValueError("warp_to_planar needs a uint8 CUDA (HIP) tensor")
+    interp = int(flags) & 7
+    if interp not in (INTER_NEAREST, INTER_LINEAR):
+        raise ValueError("unsupported interpolation flag %d" % interp)
+    if src.dim() == 2:
+        s4 = src[None, :, :, None]
+    elif src.dim() == 3:
+        s4 = src[None]
+    elif src.dim() == 4:
+        s4 = src
+    else:
+        raise ValueError("src must be (B,H,W,C), (H,W,C) or (H,W)")
+    B, H, W, C = s4.shape
+    if s4.stride(3) != 1 or s4.stride(2) != C:
+        s4 = s4.contiguous()
+    dw, dh = int(dsize[0]), int(dsize[1])
+    if M_inv_device is None:
+        M_inv_device = device_inverse(M, s4.device, inverse_given=bool(int(flags) & WARP_INVERSE_MAP))
+    n_m = M_inv_device.shape[0]
+    if n_m not in (1, B):
+        raise ValueError("got %d homographies for a batch of %d" % (n_m, B))
+    if out is None:
+        d4 = torch.empty((B, C, dh, dw), dtype=torch.float32, device=s4.device)
+    else:
+        d4 = out.reshape(B, C, dh, dw)
+        if d4.data_ptr() != out.data_ptr() or d4.dtype != torch.float32 or d4.stride(3) != 1:
+            raise ValueError("out must be a float32 (B, C, h, w) tensor with contiguous rows")
+    def per_channel(v):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (C,)))
+    sc, bi = per_channel(scale), per_channel(bias)
+    bv = None if border_value is None else per_channel(border_value)
+    stream = torch.cuda.current_stream(s4.device).cuda_stream
+    with torch.cuda.device(s4.device):
+        st = _lib.load().bevwarp_warp_planar(
+            s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C, s4.stride(0), s4.stride(1),
+            d4.stride(0) * 4, d4.stride(1) * 4, d4.stride(2) * 4, M_inv_device.data_ptr(), n_m, interp,
+            None if bv is None else bv.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
+            bi.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(stream))
+    _lib.check(st)
+    if out is not None:
+        return out
+    return d4 if src.dim() == 4 else d4[0]
+
+
 def footprint(src_hw, M, dsize, batch=None, flags=INTER_LINEAR, device="cuda"):
     """Exact count of distinct in-bounds source pixels the warp reads, per frame.
     Returns (counts int64 tensor [n], touched uint8 tensor [n, H, W])."""

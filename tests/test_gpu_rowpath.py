@@ -118,3 +118,28 @@ def test_fused_resize_warp_small_branch(W):
     two = W.warp_perspective(sm, M_small, (512, 256)).cpu().numpy()
     inside = (two.sum(axis=2) > 0) & (got.sum(axis=2) > 0)
     assert np.abs(got.astype(int) - two.astype(int))[inside].mean() < 1.5
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("c,dw,dh", [(3, 512, 80), (3, 300, 37), (1, 256, 32), (4, 512, 16), (3, 70, 5)])
+def test_planar_normalised_output(W, interp, c, dw, dh):
+    """uint8 warp written as normalised float32 channel planes in one pass == the uint8 oracle warp,
+    converted with float32 multiply-then-add (row-path tiles, ragged tiles and the short-image path)."""
+    M = wl.synth_brno_H(640, 360, dw, dh)
+    src = wl.frame(11, 360, 640, np.uint8, c)
+    mean, std = np.array([0.485, 0.456, 0.406, 0.5])[:c], np.array([0.229, 0.224, 0.225, 0.25])[:c]
+    scale, bias = 1.0 / (255.0 * std), -mean / std
+    t = torch.from_numpy(src).cuda()
+    got = W.warp_to_planar(t, M, (dw, dh), scale=scale, bias=bias, flags=interp, border_value=[9, 60, 200, 17][:c])
+    assert got.shape == (c, dh, dw) and got.dtype == torch.float32
+    ref = co.warp_perspective(src, M, (dw, dh), interp, border_value=[9, 60, 200, 17][:c]).reshape(dh, dw, c)
+    exp = ref.transpose(2, 0, 1).astype(np.float32) * scale.astype(np.float32)[:, None, None] + bias.astype(np.float32)[:, None, None]
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    # batched, default scale 1/255, preallocated output
+    frames = torch.from_numpy(np.stack([wl.frame(12 + i, 360, 640, np.uint8, c) for i in range(3)])).cuda()
+    out = torch.empty((3, c, dh, dw), dtype=torch.float32, device="cuda")
+    r = W.warp_to_planar(frames, M, (dw, dh), flags=interp, out=out)
+    assert r is out
+    for i in range(3):
+        ref = co.warp_perspective(frames[i].cpu().numpy(), M, (dw, dh), interp).reshape(dh, dw, c)
+        np.testing.assert_array_equal(out[i].cpu().numpy(), ref.transpose(2, 0, 1).astype(np.float32) * np.float32(1.0 / 255.0) + np.float32(0.0))
