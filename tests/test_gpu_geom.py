@@ -100,3 +100,35 @@ def test_composite_bev_img_matches_reference_arithmetic(golden):
     exp[exp > 255] = 255
     np.testing.assert_array_equal(got.cpu().numpy(), exp.astype(np.uint8))
     assert got.shape == (640, 320, 3) and got.dtype == torch.uint8
+
+
+def test_tracker_geometry_step_matches_host_functions():
+    """detections BEV -> world, IoU against predicted tracker boxes, gating and image centres as
+    one device step == the host functions that are pinned by the reference's own vectors (rbox_world_bev,
+    pts_world_bev) and the IoU oracle."""
+    import bev
+    from bev_amd import rbox as host_rbox
+    from bev_amd.tracker_geom import rbox_world_bev_device, tracker_geometry_step
+    calib = bev.Calib(vp1=np.array([1200.0, -300.0]), vp2=np.array([-2500.0, -150.0]), pp=np.array([959.5, 539.5]), height=8, u_size=1920, v_size=1080)
+    center = calib.gen_center_in_world()
+    bspec = bev.BEVWorldSpec(u_size=512, v_size=512, u_axis="y", v_axis="-x", x_size=64, y_size=64, x_min=center[0] - 20, y_min=center[1] - 32)
+    H_world_bev = bspec.gen_H_world_bev()
+    H_img_world = np.linalg.inv(calib.gen_H_world_img())
+    rng = np.random.default_rng(21)
+    n, m = 300, 257
+    dets_bev = np.column_stack([rng.uniform(0, 512, (n, 2)), rng.uniform(12, 18, n), rng.uniform(28, 48, n), rng.uniform(-np.pi, np.pi, n)])
+    dets_world_host = host_rbox.rbox_world_bev(dets_bev, H_world_bev, "bev")
+    # trackers: the detections' own world boxes, jittered (so a band of pairs overlaps), plus strays
+    trks = np.vstack([dets_world_host[:200] + rng.normal(0, [0.4, 0.4, 0.05, 0.1, 0.05], (200, 5)),
+                      np.column_stack([rng.uniform(-30, 60, (57, 2)), rng.uniform(1.6, 2.2, 57), rng.uniform(3.5, 6, 57), rng.uniform(-np.pi, np.pi, 57)])])
+    out = tracker_geometry_step(dets_bev, trks, H_world_bev, iou_threshold=0.3, H_img_world=H_img_world)
+    np.testing.assert_allclose(out["dets_world"].cpu().numpy(), dets_world_host, rtol=1e-12, atol=1e-12)
+    exp_iou = co.rbox_iou(out["dets_world"].cpu().numpy(), trks)
+    np.testing.assert_allclose(out["iou"].cpu().numpy(), exp_iou, rtol=0, atol=1e-12)
+    assert (exp_iou > 0.3).sum() > 100
+    np.testing.assert_array_equal(out["candidates"].cpu().numpy(), out["iou"].cpu().numpy() > 0.3)
+    np.testing.assert_allclose(out["dets_img"].cpu().numpy(), host_rbox.rbox_world_img(dets_world_host, H_img_world), rtol=1e-10, atol=1e-8)
+    # and back: world -> bev is the inverse map
+    back = rbox_world_bev_device(out["dets_world"], np.linalg.inv(H_world_bev), "world").cpu().numpy()
+    np.testing.assert_allclose(back[:, :4], dets_bev[:, :4], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.angle(np.exp(1j * (back[:, 4] - dets_bev[:, 4]))), 0, atol=1e-9)

@@ -62,3 +62,48 @@ for dt, tdt in (("f32", torch.float32), ("f64", torch.float64)):
     mean, mn = timeit(lambda: rbox_iou(a, b), n=200)
     print(json.dumps({"config": "configs[4] IoU half: 512 x 512 rotated-box IoU, %s" % dt, "us": round(mean * 1e6, 2), "us_min": round(mn * 1e6, 2),
                       "Mpairs_per_s": round(512 * 512 / mean / 1e6, 1)}))
+
+# configs[4], whole: one camera frame's BEV warp plus the tracker's geometry step on 512 detections x 512 tracks
+# (per-camera sequential state: "replicas only" across GPUs)
+from bev_amd import warp as _warp  # noqa: E402
+from bev_amd.tracker_geom import tracker_geometry_step  # noqa: E402
+from tests import workloads as _wl  # noqa: E402
+
+Hk = _wl.keystone_H(1920, 1080, 1024, 1024)
+frames = [torch.from_numpy(_wl.frame(i, 1080, 1920, np.uint8)).cuda() for i in range(8)]
+outs = [torch.empty((1024, 1024, 3), dtype=torch.uint8, device="cuda") for _ in range(8)]
+minv = _warp.device_inverse(Hk, frames[0].device)
+H_world_bev = np.array([[0.0, 0.0625, -10.0], [-0.0625, 0.0, 40.0], [0, 0, 1.0]])
+dets_bev = torch.from_numpy(np.column_stack([rng.uniform(0, 1024, (512, 2)), rng.uniform(25, 35, 512), rng.uniform(56, 96, 512), rng.uniform(-np.pi, np.pi, 512)])).cuda()
+trks = torch.from_numpy(boxes(512)).cuda()
+kk = [0]
+
+
+def tracker_step():
+    i = kk[0] % 8
+    _warp.warp_perspective(frames[i], None, (1024, 1024), out=outs[i], M_inv_device=minv)
+    tracker_geometry_step(dets_bev, trks, H_world_bev, 0.3)
+    kk[0] += 1
+
+
+mean, mn = timeit(tracker_step, n=100)
+print(json.dumps({"config": "configs[4]: one 1080p -> 1024^2 uint8 bilinear warp + tracker geometry step (512 dets x 512 tracks, float64)",
+                  "us": round(mean * 1e6, 1), "us_min": round(mn * 1e6, 1), "frames_per_s": round(1 / mean, 1)}))
+
+# the same step captured once in a HIP graph and replayed (the launch-bound form a per-camera loop would run)
+try:
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            tracker_step()
+    torch.cuda.current_stream().wait_stream(s)
+    kk[0] = 0
+    with torch.cuda.graph(g):
+        tracker_step()
+    mean, mn = timeit(g.replay, n=100)
+    print(json.dumps({"config": "configs[4]: the same step replayed from a HIP graph", "us": round(mean * 1e6, 1), "us_min": round(mn * 1e6, 1),
+                      "frames_per_s": round(1 / mean, 1)}))
+except Exception as e:  # graph capture is an optimisation of the harness, not of the path
+    print(json.dumps({"config": "configs[4]: HIP graph replay", "error": "%s: %s" % (type(e).__name__, e)}))

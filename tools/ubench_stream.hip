@@ -16,6 +16,7 @@
 // MODE 6: as MODE 0 with the address rounded down to 4 B and 12 B loaded (dwordx3): aligned windows that cover the 6 bytes
 // MODE 7: as MODE 0 with the address rounded down to 4 B, 8 B loaded (dwordx2 aligned; not enough bytes, timing only)
 // MODE 8: as MODE 0 with the address rounded down to 8 B and 16 B loaded (dwordx4... aligned to 8)
+// MODE 9: as MODE 3 with the 24 bytes fetched as dwordx3 + dwordx3
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ buf, uint32_t* sink, int rows_per_wave, int64_t row_stride, int64_t wave_stride) {
     const int lane = threadIdx.x & 63;
@@ -52,6 +53,12 @@ __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ buf, uint32
             } else if (MODE == 8) {
                 const uint8_t* q = r + (i >> 1) * 192 + (i & 1) * row_stride + ((lane * 3 + 1) & ~7);
                 __builtin_memcpy(&v[i], q, 16);
+            } else if (MODE == 9) {
+                const uint8_t* q = r + (i >> 1) * 768 + (i & 1) * row_stride + lane * 12 + 4;
+                __builtin_memcpy(&v[i], q, 12);
+                uint32_t t3[3];
+                __builtin_memcpy(t3, q + 12, 12);
+                w[i] = make_uint2(t3[0] ^ t3[2], t3[1]);
             } else if (MODE == 4) {
                 v[i] = *reinterpret_cast<const uint4*>(r + i * 1024 + lane * 16);
             } else {
@@ -105,6 +112,7 @@ int main() {
     run<3>("8 x (dwordx4+dwordx2), 12 B lane stride (f32 bilinear gather)", buf, sink, cus, 2 * 3096.0, 16);
     run<4>("8 x dwordx4 coalesced (8 KiB per row)", buf, sink, cus, 8192.0, 8);
     run<5>("8 x dwordx2 coalesced aligned (4 KiB per row)", buf, sink, cus, 4096.0, 8);
+    run<9>("8 x (dwordx3+dwordx3), 12 B lane stride (f32 bilinear gather)", buf, sink, cus, 2 * 3096.0, 16);
     run<6>("8 x dwordx3 4-B aligned windows, ~3 B lane stride", buf, sink, cus, 2 * 776.0, 8);
     run<7>("8 x dwordx2 4-B aligned, ~3 B lane stride (timing only)", buf, sink, cus, 2 * 776.0, 8);
     run<8>("8 x dwordx4 8-B aligned windows, ~3 B lane stride", buf, sink, cus, 2 * 776.0, 8);
