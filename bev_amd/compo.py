@@ -2,11 +2,15 @@
 
 composite_reg_img   alpha blend  fg * m + bg * (1 - m), m = mask / 255, rounded and clipped to uint8 (compo.py:5-24)
 composite_bev_img   warp background, foreground and mask into the BEV (three warps through the HIP path) and blend
-                    (compo.py:26-49).  All pixels stay on the GPU; the blend is float64 like the reference.
+                    (compo.py:26-49).  All pixels stay on the GPU; the blend is one HIP launch in float64 like the reference
+                    (bevwarp_composite).
 """
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib
 from .homo import homo_from_KRt
 from .warp import warp_perspective
 
@@ -22,10 +26,15 @@ def composite_reg_img(bg, fg, fg_mask, bw_mode=False, device="cuda"):
     cv2.cvtColor for it)."""
     if bw_mode:
         raise NotImplementedError("bw_mode needs a BGR->gray conversion outside the warp path")
-    bg, fg, fg_mask = (_as_cuda(x, device).to(torch.float64) for x in (bg, fg, fg_mask))
-    m = fg_mask / 255
-    compo = (fg * m + bg * (1 - m)).round()
-    return compo.clamp_(max=255).to(torch.uint8)
+    bg, fg, fg_mask = (_as_cuda(x, device).contiguous() for x in (bg, fg, fg_mask))
+    if not (bg.dtype == fg.dtype == fg_mask.dtype == torch.uint8) or not (bg.shape == fg.shape == fg_mask.shape):
+        raise ValueError("composite_reg_img needs three uint8 images of one shape")
+    out = torch.empty_like(bg)
+    stream = torch.cuda.current_stream(bg.device).cuda_stream
+    with torch.cuda.device(bg.device):
+        _lib.check(_lib.load().bevwarp_composite(bg.data_ptr(), fg.data_ptr(), fg_mask.data_ptr(), out.data_ptr(), bg.numel(),
+                                                 ctypes.c_void_p(stream)))
+    return out
 
 
 def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_size, y_size, bw_mode=False, device="cuda"):

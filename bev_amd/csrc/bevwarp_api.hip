@@ -243,6 +243,12 @@ int bevwarp_warp_planar(const void* src, void* dst, int batch, int src_h, int sr
                      M_inv, m_count, BEVWARP_U8, interp, border_value, stream, &po);
 }
 
+int bevwarp_composite(const void* bg, const void* fg, const void* mask, void* out, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!bg || !fg || !mask || !out))) return BEVWARP_ERR_BAD_ARG;
+    const hipError_t e = bevwarp::launch_composite((const uint8_t*)bg, (const uint8_t*)fg, (const uint8_t*)mask, (uint8_t*)out, n, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
 int bevwarp_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* M_inv, int m_count,
                       int interp, void* stream) {
     if (!touched || !M_inv || batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;

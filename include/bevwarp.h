@@ -11,6 +11,8 @@
  *   bevwarp_warp_planar     the same warp of 8-bit frames, written as normalised float32 channel planes in the same
  *                             pass (the layout step between vis_homo.py:89 and a detector's input;
  *                             the reference leaves it to its callers)
+ *   bevwarp_composite       composite_reg_img(bg, fg, fg_mask), bev/tool/compo.py:5-24 (the blend after the three warps
+ *                             of composite_bev_img, :26-49)
  *   bevwarp_footprint       -- measurement aid (SURVEY.md 8(d) "footprint_px"), no reference twin
  *   bevwarp_project_points  pts_world_bev(pts_src, H), bev/rbox.py:136-151; rbox_world_img, :221-226;
  *                             Calib.gen_center_in_world, bev/calib.py:135-138
@@ -95,6 +97,13 @@ int bevwarp_warp_planar(const void *src, void *dst, int batch, int src_h, int sr
                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,
                         int64_t dst_row_stride, const double *M_inv, int m_count, int interp, const double *border_value /*HOST*/,
                         const double *scale /*HOST*/, const double *bias /*HOST*/, void *stream);
+
+/*
+ * out[i] = uint8(min(round_half_even(fg[i] * (mask[i] / 255) + bg[i] * (1 - mask[i] / 255)), 255)) for i in [0, n), computed in
+ * float64 like the reference's numpy expression.  Device uint8 arrays of n bytes each (images of equal shape, any
+ * channel count, flattened); `out` may alias `bg` or `fg`.
+ */
+int bevwarp_composite(const void *bg, const void *fg, const void *mask, void *out, int64_t n, void *stream);
 
 /*
  * Marks every in-bounds source pixel that any tap of any destination pixel of the same warp would
