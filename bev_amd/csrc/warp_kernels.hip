@@ -1,24 +1,27 @@
-// warp_kernels.hip -- batched BEV homography warp for MI355X (gfx950, wave64).  See DESIGN.md.
+// warp_kernels.hip -- batched BEV homography warp for MI355X (gfx950, wave64).  See DESIGN.md section 4.
 //
 // Replaces the per-frame cv2.warpPerspective call of the reference (vis_homo.py:89,91;
-// bev/tool/compo.py:38,46,47).  One workgroup (256 threads = 4 waves) produces one TW x TH tile of
-// one BEV frame (TW = 64 for 8-bit pixels, 32 for float pixels):
-//   1. four lanes map the tile's corner pixels; their source bounding box (+ margin) is the tile's
-//      source region; one wave tabulates the per-row terms of the homography (M01*y+M02, ...),
-//   2. the region is staged into LDS with coalesced row loads (u8x3 is widened to 4 B / pixel so a
-//      tap is one aligned dword; other formats keep their natural layout, 16 B per load),
-//   3. every lane owns PPL consecutive BEV pixels of one row.  Coordinates are float64.  The fast
-//      path replaces the IEEE division by rcp + Newton (one reciprocal shared by the lane's pixels)
-//      and rounds through the float64 mantissa; it is provably equal to the reference's rounding
-//      chain unless the coordinate lies within 2^-19 of a rounding tie -- those pixels (and anything
-//      non-finite or far outside) re-run the exact chain, operation for operation.
-//   4. taps come from LDS; 8-bit blending is exact integer arithmetic on v_dot4_u32_u8.
-// Pixels whose taps leave the staged region (image border) read global memory with per-tap bounds
-// checks; tiles whose region exceeds the LDS budget are processed in 16-row bands, and as a last
-// resort unstaged.
+// bev/tool/compo.py:38,46,47).  Three kernels share the coordinate chain, the blending arithmetic and the
+// guarded border sampling and differ in how source taps reach registers:
 //
-// No MFMA: this is a gather.  The 8-bit kernel is bound by vector-ALU issue (float64 coordinate
-// chain + blending), the float kernel by HBM.
+//   warp_gather (default)  one wave = one TW-pixel row segment (TW = 256 for 8-bit, 128 for float pixels); pixel j
+//       of lane l is x0 + 64 j + l.  Every row is classified from its two end pixels (FAST / OUT / EDGE / SLOW);
+//       FAST rows load their taps straight from global memory (aligned 12-byte windows + funnel shift for 8-bit
+//       RGB), blend, transpose through a wave-private LDS row and store contiguously, software-pipelined one row
+//       ahead.  No workgroup barrier.
+//   warp_tiles  (BEVWARP_MODE=1)  the workgroup stages the source bounding box of a 64 x 32 tile into LDS with
+//       coalesced row loads (8-bit RGB widened to 4 B / pixel; other formats by LDS-DMA), tabulates the row terms
+//       in LDS and samples from LDS; 16-row bands when the box exceeds the LDS budget.
+//   warp_wave   (BEVWARP_MODE=3)  every wave stages the box of its own 64 x 4 block into a private LDS slot.
+//
+// Coordinates are float64.  The fast path replaces the IEEE division by rcp + Newton (one reciprocal shared by the
+// lane's pixels) and rounds through the float64 mantissa; it equals the reference's rounding chain unless the
+// coordinate lies within 2^-19 of a rounding boundary -- those pixels (and anything non-finite or far outside) re-run
+// the exact chain, operation for operation.  8-bit blending is exact integer arithmetic on v_dot4_u32_u8; float
+// blending keeps the reference's operation order (FMA contraction off).
+//
+// No MFMA: this is a gather.  The float kernel is bound by HBM; the 8-bit kernels by the texture path's cost per
+// gather instruction and by vector-ALU issue (float64 coordinate chain + blending), DESIGN.md section 6.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
