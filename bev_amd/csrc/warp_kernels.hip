@@ -1128,9 +1128,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             const bool in = (uint32_t)(sxa - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(sxb - kM) <= (uint32_t)(sxw_lim - 2 * kM) &&
                             (uint32_t)(sya - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syb - kM) <= (uint32_t)(sy_lim - 2 * kM) &&
                             sxw_lim >= 2 * kM && sy_lim >= 2 * kM;
-            const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
-            // kEdge: the coordinates are good, taps need guards
-            const int cls = !(e_bad == 0 && w_ok) ? kSlow : (in ? kFast : ((out && fill_ok) ? kOut : kEdge));
+            int cls = kFast;
+            if (__builtin_expect(!(e_bad == 0 && w_ok && in), 0)) {  // (the common class costs no further scalar work)
+                const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
+                // kEdge: the coordinates are good, taps need guards
+                cls = !(e_bad == 0 && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
+            }
             if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
 #pragma unroll
                 for (int j = 0; j < PPL; j++) {
