@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         bool fill_ok = true;
         if (sizeof(T) == 4 && INTERP == kLinear)
             for (int k = 0; k < C; k++) fill_ok = fill_ok && __float_as_uint(a.bval_f[k]) == 0u;
+        int out_side = 0;  // set by coords_s for an OUT row: which frame edge the segment lies beyond, and the sign of W
         auto coords_s = [&](int y, uint32_t (&RX)[PPL], uint32_t (&RY)[PPL]) -> int {
             double W[PPL], Xn[PPL], Yn[PPL], r[PPL];
             const double dy = (double)y;
@@ -1133,6 +1134,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
                 // kEdge: the coordinates are good, taps need guards
                 cls = !(e_bad == 0 && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
+                out_side = ((sxa <= -3 && sxb <= -3) ? 1 : (sxa > a.src_w && sxb > a.src_w) ? 2 : (sya <= -3 && syb <= -3) ? 3 : 4) | (int)((wa >> 31) << 3);
             }
             if (tie == 0) {  // rare: within 2^-19 of a rounding tie -> the exact chain decides
 #pragma unroll
@@ -1399,6 +1401,20 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         uint32_t S0[PPL], S1[PPL];
         uint4 out[NQ];
         int cls_c = coords_s(yf, RXc, RYc), cls_n = kSlow;
+        if (cls_c == kOut && yf + RSTEP <= y_end) {
+            // The wave's first row lies beyond a frame edge: probe its last row.  When that one lies beyond the same
+            // edge with W of the same sign, the rows between them map into the convex hull of the two segments and
+            // see nothing of the frame either: fill them without computing a coordinate.  (Footprints like the
+            // Brno BEV have a third of their rows outside; a wave whose first row is inside never pays for this.)
+            const int side0 = out_side;
+            const int y_probe = yf + ((y_end - yf) / RSTEP) * RSTEP;
+            if (coords_s(y_probe, RXn, RYn) == kOut && out_side == side0) {
+                fill_s();
+                read_back(out);
+                for (int y = yf; y <= y_end; y += RSTEP) store_s(y, out);
+                return;
+            }
+        }
         issue_s(cls_c, RXc, RYc, u0, u1, S0, S1);
         // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt
         // retires in issue order, so a store issued before a row's loads would have to reach L2 before that row's
