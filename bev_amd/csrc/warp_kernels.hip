@@ -209,7 +209,10 @@ struct Pixel<uint8_t, C> {
     uint32_t packed;
 };
 
-// One pixel straight from global memory with per-tap bounds checks (border, fallback tiles).
+// One pixel straight from global memory with per-tap bounds checks (border, fallback tiles).  Every tap is loaded
+// from the CLAMPED coordinate (always a valid address) and replaced by the border value afterwards when its true
+// coordinate is outside: the loads are unconditional, so they all issue before the first wait (conditional loads
+// compile to one memory round trip each).
 template <typename T, int C, int INTERP>
 __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, int Y) {
     const uint8_t* __restrict__ frame = a.frame;
@@ -217,10 +220,14 @@ __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, in
     if constexpr (sizeof(T) == 1) out.packed = 0;
     if (INTERP == kNearest) {
         const bool in = (unsigned)X < (unsigned)a.w && (unsigned)Y < (unsigned)a.h;
-        const T* p = reinterpret_cast<const T*>(frame + (int64_t)Y * a.rs) + (int64_t)X * C;
+        const int cx = min(max(X, 0), a.w - 1), cy = min(max(Y, 0), a.h - 1);
+        const T* p = reinterpret_cast<const T*>(frame + (int64_t)cy * a.rs) + (int64_t)cx * C;
+        T t[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) t[k] = p[k];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const T v = in ? p[k] : border_of<T>(a, k);
+            const T v = in ? t[k] : border_of<T>(a, k);
             if constexpr (sizeof(T) == 1)
                 out.packed |= (uint32_t)v << (8 * k);
             else
@@ -231,17 +238,27 @@ __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, in
     const int sx = X >> kInterBits, sy = Y >> kInterBits, fx = X & 31, fy = Y & 31;
     const bool xin0 = (unsigned)sx < (unsigned)a.w, xin1 = (unsigned)(sx + 1) < (unsigned)a.w;
     const bool yin0 = (unsigned)sy < (unsigned)a.h, yin1 = (unsigned)(sy + 1) < (unsigned)a.h;
-    const T* r0 = reinterpret_cast<const T*>(frame + (int64_t)sy * a.rs) + (int64_t)sx * C;
-    const T* r1 = reinterpret_cast<const T*>(frame + (int64_t)(sy + 1) * a.rs) + (int64_t)sx * C;
+    const int cx0 = min(max(sx, 0), a.w - 1), cx1 = min(max(sx + 1, 0), a.w - 1);
+    const int cy0 = min(max(sy, 0), a.h - 1), cy1 = min(max(sy + 1, 0), a.h - 1);
+    const T* r0 = reinterpret_cast<const T*>(frame + (int64_t)cy0 * a.rs);
+    const T* r1 = reinterpret_cast<const T*>(frame + (int64_t)cy1 * a.rs);
+    T t00[C], t01[C], t10[C], t11[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        t00[k] = r0[(int64_t)cx0 * C + k];
+        t01[k] = r0[(int64_t)cx1 * C + k];
+        t10[k] = r1[(int64_t)cx0 * C + k];
+        t11[k] = r1[(int64_t)cx1 * C + k];
+    }
     float w00 = 0, w01 = 0, w10 = 0, w11 = 0;
     if constexpr (sizeof(T) == 4) weights_f32(fx, fy, w00, w01, w10, w11);
 #pragma unroll
     for (int k = 0; k < C; k++) {
         const T b = border_of<T>(a, k);
-        const T v00 = (xin0 && yin0) ? r0[k] : b;
-        const T v01 = (xin1 && yin0) ? r0[k + C] : b;
-        const T v10 = (xin0 && yin1) ? r1[k] : b;
-        const T v11 = (xin1 && yin1) ? r1[k + C] : b;
+        const T v00 = (xin0 && yin0) ? t00[k] : b;
+        const T v01 = (xin1 && yin0) ? t01[k] : b;
+        const T v10 = (xin0 && yin1) ? t10[k] : b;
+        const T v11 = (xin1 && yin1) ? t11[k] : b;
         if constexpr (sizeof(T) == 1)
             out.packed |= blend_u8(v00, v01, v10, v11, fx, fy) << (8 * k);
         else
