@@ -107,3 +107,17 @@ try:
                       "frames_per_s": round(1 / mean, 1)}))
 except Exception as e:  # graph capture is an optimisation of the harness, not of the path
     print(json.dumps({"config": "configs[4]: HIP graph replay", "error": "%s: %s" % (type(e).__name__, e)}))
+
+# PCIe-inclusive rate of the numpy drop-in (bev.warp.warpPerspective: host frame up, BEV frame down, pageable memory)
+import time as _time  # noqa: E402
+
+img = _wl.frame(0, 1080, 1920, np.uint8)
+for _ in range(3):
+    _warp.warpPerspective(img, Hk, (1024, 1024))
+t0 = _time.perf_counter()
+n_rep = 20
+for _ in range(n_rep):
+    res = _warp.warpPerspective(img, Hk, (1024, 1024))
+dt_host = (_time.perf_counter() - t0) / n_rep
+print(json.dumps({"config": "numpy drop-in warpPerspective, one 1080p uint8 frame -> 1024^2, host to host (PCIe-inclusive)",
+                  "ms": round(dt_host * 1e3, 3), "Mpix_per_s": round(1024 * 1024 / dt_host / 1e6, 1)}))
