@@ -143,3 +143,29 @@ def test_planar_normalised_output(W, interp, c, dw, dh):
     for i in range(3):
         ref = co.warp_perspective(frames[i].cpu().numpy(), M, (dw, dh), interp).reshape(dh, dw, c)
         np.testing.assert_array_equal(out[i].cpu().numpy(), ref.transpose(2, 0, 1).astype(np.float32) * np.float32(1.0 / 255.0) + np.float32(0.0))
+
+
+def test_graphed_step_replays_bit_exactly(W):
+    """bev_amd.graph.GraphedStep: warp + composite + tracker geometry captured once, replayed on new inputs."""
+    from bev_amd.compo import composite_reg_img
+    from bev_amd.graph import GraphedStep
+    M = wl.synth_brno_H(640, 360, 512, 64)
+    src = torch.zeros((360, 640, 3), dtype=torch.uint8, device="cuda")
+    out = torch.empty((64, 512, 3), dtype=torch.uint8, device="cuda")
+    minv = W.device_inverse(M, src.device)
+
+    def step():
+        W.warp_perspective(src, None, (512, 64), out=out, M_inv_device=minv)
+        return composite_reg_img(out, out.flip(0), out.flip(1))
+
+    g = GraphedStep(step)
+    for i in range(3):
+        f = wl.frame(20 + i, 360, 640, np.uint8)
+        src.copy_(torch.from_numpy(f).cuda())
+        blended = g.replay()
+        torch.cuda.synchronize()
+        exp = co.warp_perspective(f, M, (512, 64), 1)
+        np.testing.assert_array_equal(out.cpu().numpy(), exp)
+        m = exp[:, ::-1].astype(float) / 255
+        ref = (exp[::-1].astype(float) * m + exp.astype(float) * (1 - m)).round()
+        np.testing.assert_array_equal(blended.cpu().numpy(), np.minimum(ref, 255).astype(np.uint8))

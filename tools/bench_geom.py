@@ -92,16 +92,9 @@ print(json.dumps({"config": "configs[4]: one 1080p -> 1024^2 uint8 bilinear warp
 
 # the same step captured once in a HIP graph and replayed (the launch-bound form a per-camera loop would run)
 try:
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            tracker_step()
-    torch.cuda.current_stream().wait_stream(s)
+    from bev_amd.graph import GraphedStep  # noqa: E402
     kk[0] = 0
-    with torch.cuda.graph(g):
-        tracker_step()
+    g = GraphedStep(tracker_step)
     mean, mn = timeit(g.replay, n=100)
     print(json.dumps({"config": "configs[4]: the same step replayed from a HIP graph", "us": round(mean * 1e6, 1), "us_min": round(mn * 1e6, 1),
                       "frames_per_s": round(1 / mean, 1)}))
@@ -121,3 +114,22 @@ for _ in range(n_rep):
 dt_host = (_time.perf_counter() - t0) / n_rep
 print(json.dumps({"config": "numpy drop-in warpPerspective, one 1080p uint8 frame -> 1024^2, host to host (PCIe-inclusive)",
                   "ms": round(dt_host * 1e3, 3), "Mpix_per_s": round(1024 * 1024 / dt_host / 1e6, 1)}))
+
+# the per-camera frame loop of vis_homo.py:85-91 on resident frames, one launch per frame, back to back
+kk[0] = 0
+
+
+def eager_frame():
+    i = kk[0] % 8
+    _warp.warp_perspective(frames[i], None, (1024, 1024), out=outs[i], M_inv_device=minv)
+    kk[0] += 1
+
+
+torch.cuda.synchronize()
+t0 = _time.perf_counter()
+for _ in range(2000):
+    eager_frame()
+torch.cuda.synchronize()
+dt1 = (_time.perf_counter() - t0) / 2000
+print(json.dumps({"config": "one resident 1080p uint8 frame -> 1024^2 per call, back to back", "us_per_frame": round(dt1 * 1e6, 1),
+                  "frames_per_s": round(1 / dt1, 1)}))
