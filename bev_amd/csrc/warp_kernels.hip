@@ -145,22 +145,30 @@ __device__ __forceinline__ void weights_f32(int fx, int fy, float& w00, float& w
 // Packed 8-bit blend of up to 4 channels: p?? are pixels with channel k in byte k.  Horizontal sums
 // with v_dot4_u32_u8 (weights 32-fx, fx <= 32), vertical with 24-bit mads scaled by 64 so that the
 // result byte sits in bits 16..23:  ((h0*wy0 + h1*wy1) * 64 + 2^15) >> 16 == (S + 512) >> 10.
+// vertical stage of the 8-bit blend: wy0 * top + wy1 * bot + 2^15 as ONE v_dot2_u32_u16 on the packed pair (top and bot
+// are horizontal sums <= 8160, wy0 + wy1 = 2048)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t vblend_u8(uint32_t top, uint32_t bot, uint32_t wy01) {
+    const uint32_t tb = top | (bot << 16);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, tb), __builtin_bit_cast(u16x2, wy01), 32768u, false);
+}
+
 template <int C>
 __device__ __forceinline__ uint32_t blend_u8_packed(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, uint32_t fx, uint32_t fy) {
     const uint32_t wlo = fx * 255u + 32u;         // bytes (32 - fx, fx, 0, 0)
     const uint32_t whi = wlo << 16;               // bytes (0, 0, 32 - fx, fx)
-    const uint32_t wy1 = fy << 6, wy0 = 2048u - wy1;
+    const uint32_t wy01 = fy * 0x3fffc0u + 2048u;  // halves (2048 - 64 fy, 64 fy): the vertical weights as a packed pair
     // (a.k, b.k, a.k', b.k') for channel pairs (0,1) and (2,3)
     const uint32_t t01 = __builtin_amdgcn_perm(p01, p00, 0x05010400u);
     const uint32_t b01 = __builtin_amdgcn_perm(p11, p10, 0x05010400u);
     uint32_t s[4];
-    s[0] = __umul24(__builtin_amdgcn_udot4(t01, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b01, wlo, 0u, false), wy1) + 32768u);
-    if (C > 1) s[1] = __umul24(__builtin_amdgcn_udot4(t01, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b01, whi, 0u, false), wy1) + 32768u);
+    s[0] = vblend_u8(__builtin_amdgcn_udot4(t01, wlo, 0u, false), __builtin_amdgcn_udot4(b01, wlo, 0u, false), wy01);
+    if (C > 1) s[1] = vblend_u8(__builtin_amdgcn_udot4(t01, whi, 0u, false), __builtin_amdgcn_udot4(b01, whi, 0u, false), wy01);
     if (C > 2) {
         const uint32_t t23 = __builtin_amdgcn_perm(p01, p00, 0x07030602u);
         const uint32_t b23 = __builtin_amdgcn_perm(p11, p10, 0x07030602u);
-        s[2] = __umul24(__builtin_amdgcn_udot4(t23, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b23, wlo, 0u, false), wy1) + 32768u);
-        if (C > 3) s[3] = __umul24(__builtin_amdgcn_udot4(t23, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(b23, whi, 0u, false), wy1) + 32768u);
+        s[2] = vblend_u8(__builtin_amdgcn_udot4(t23, wlo, 0u, false), __builtin_amdgcn_udot4(b23, wlo, 0u, false), wy01);
+        if (C > 3) s[3] = vblend_u8(__builtin_amdgcn_udot4(t23, whi, 0u, false), __builtin_amdgcn_udot4(b23, whi, 0u, false), wy01);
     }
     // gather byte 2 of every sum
     uint32_t out = (C > 1) ? __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u) : ((s[0] >> 16) & 0xffu);
@@ -182,12 +190,12 @@ struct SrcView {
 // at the left tap (left pixel = bytes 0 1 2, right pixel = bytes 3 4 5); the byte selects do the unpacking.
 __device__ __forceinline__ uint32_t blend_u8_rgb_window(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t fx, uint32_t fy) {
     const uint32_t wlo = fx * 255u + 32u, whi = wlo << 16;
-    const uint32_t wy1 = fy << 6, wy0 = 2048u - wy1;
+    const uint32_t wy01 = fy * 0x3fffc0u + 2048u;  // halves (2048 - 64 fy, 64 fy)
     const uint32_t t01 = __builtin_amdgcn_perm(a1, a0, 0x04010300u), u01 = __builtin_amdgcn_perm(b1, b0, 0x04010300u);  // L.c0 R.c0 L.c1 R.c1
     const uint32_t t2 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0502u), u2 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0502u);    // L.c2 R.c2 0 0
-    const uint32_t s0 = __umul24(__builtin_amdgcn_udot4(t01, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u01, wlo, 0u, false), wy1) + 32768u);
-    const uint32_t s1 = __umul24(__builtin_amdgcn_udot4(t01, whi, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u01, whi, 0u, false), wy1) + 32768u);
-    const uint32_t s2 = __umul24(__builtin_amdgcn_udot4(t2, wlo, 0u, false), wy0) + (__umul24(__builtin_amdgcn_udot4(u2, wlo, 0u, false), wy1) + 32768u);
+    const uint32_t s0 = vblend_u8(__builtin_amdgcn_udot4(t01, wlo, 0u, false), __builtin_amdgcn_udot4(u01, wlo, 0u, false), wy01);
+    const uint32_t s1 = vblend_u8(__builtin_amdgcn_udot4(t01, whi, 0u, false), __builtin_amdgcn_udot4(u01, whi, 0u, false), wy01);
+    const uint32_t s2 = vblend_u8(__builtin_amdgcn_udot4(t2, wlo, 0u, false), __builtin_amdgcn_udot4(u2, wlo, 0u, false), wy01);
     return __builtin_amdgcn_perm(s2, __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), 0x0c060100u);
 }
 
