@@ -859,7 +859,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // (register budget: 4 waves per SIMD -- what the FAST row loop needs without spilling; the rare row
 // classes may spill)
-template <typename T, int C, int INTERP>
+// RS4: the source row stride is a multiple of 4 bytes (both tap rows of a pixel then share one window alignment)
+template <typename T, int C, int INTERP, bool RS4 = false>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 1 ? (C == 3 && INTERP == kLinear ? 3 : 4) : BEVWARP_F32_WAVES))) void warp_gather(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int GX = kGatherLX, GY = 64 / kGatherLX, GROWS = GY * (kWG / 64);  // lanes along x / y, rows per pass
@@ -1063,6 +1064,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const int sxw_lim = (int)(((int64_t)a.src_w * PBs - WINB) / PBs);  // largest sx with sx*PBs + WINB <= w*PBs
         const uint32_t fa = kAligned ? (uint32_t)(reinterpret_cast<uintptr_t>(frame) & 3u) : 0u;
         const uint8_t* frame_al = frame - fa;  // 4-byte aligned (frames need not be)
+        const uint8_t* frame_al_r1 = frame_al + rs32;
         // Row terms.  The reference's chain is X0 = (M0*bx + M1*y) + M2, X = X0 + M0*(x - bx) per evaluation block;
         // the fast chain below only has to land within 2^-20 of a coordinate unit of it (anything closer than
         // 2^-19 to a rounding boundary is redone exactly), which leaves ~12 bits of slack over float64 rounding.
@@ -1193,7 +1195,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 for (int k = 0; k < WINB / 4; k++) t0[j].w[k] = off + k, t1[j].w[k] = off ^ k;
                 S0[j] = S1[j] = off;
 #else
-                if constexpr (kAligned) {
+                if constexpr (kAligned && RS4) {  // second tap row: same window alignment, scalar base + row stride
+                    const uint32_t offa = off & ~3u;
+                    __builtin_memcpy(&t0[j], frame_al + offa, WINB);
+                    __builtin_memcpy(&t1[j], frame_al_r1 + offa, WINB);
+                    S0[j] = S1[j] = off << 3;  // funnel-shift amount (v_alignbit reads bits 4:0)
+                } else if constexpr (kAligned) {
                     const uint32_t off1 = off + rs_eff;
                     __builtin_memcpy(&t0[j], frame_al + (off & ~3u), WINB);
                     __builtin_memcpy(&t1[j], frame_al + (off1 & ~3u), WINB);
@@ -1765,7 +1772,10 @@ hipError_t launch_tc(const WarpArgs& a, int interp, dim3 grid, size_t lds, hipSt
         if (interp == kNearest)
             hipLaunchKernelGGL((warp_gather<T, C, kNearest>), grid, dim3(kWG), gather_pad_lds(), stream, a);
         else
-            hipLaunchKernelGGL((warp_gather<T, C, kLinear>), grid, dim3(kWG), gather_pad_lds(), stream, a);
+            if (sizeof(T) == 1 && C == 3 && a.src_rs % 4 == 0)
+                hipLaunchKernelGGL((warp_gather<T, C, kLinear, sizeof(T) == 1 && C == 3>), grid, dim3(kWG), gather_pad_lds(), stream, a);
+            else
+                hipLaunchKernelGGL((warp_gather<T, C, kLinear>), grid, dim3(kWG), gather_pad_lds(), stream, a);
         return hipGetLastError();
     }
     if (interp == kNearest)

@@ -169,3 +169,18 @@ def test_graphed_step_replays_bit_exactly(W):
         m = exp[:, ::-1].astype(float) / 255
         ref = (exp[::-1].astype(float) * m + exp.astype(float) * (1 - m)).round()
         np.testing.assert_array_equal(blended.cpu().numpy(), np.minimum(ref, 255).astype(np.uint8))
+
+
+@pytest.mark.parametrize("sw", [637, 638, 639, 640])
+def test_row_strides_of_every_alignment(W, sw):
+    """8-bit RGB bilinear fetches aligned 12-byte windows: source row strides of every residue mod 4 (the two tap
+    rows of a pixel share their alignment only when the stride is a multiple of 4), and an odd frame base."""
+    M = wl.synth_brno_H(1920, 1080, 512, 48) @ np.diag([1920 / sw, 1080 / 359, 1.0])
+    src = wl.frame(30, 359, sw, np.uint8)
+    both(W, src, M, (512, 48), 1)
+    buf = torch.zeros(359 * sw * 3 + 8, dtype=torch.uint8, device="cuda")
+    for shift in (1, 2, 3):
+        view = buf[shift:shift + 359 * sw * 3].view(359, sw, 3)
+        view.copy_(torch.from_numpy(src))
+        got = W.warp_perspective(view, M, (512, 48)).cpu().numpy()
+        np.testing.assert_array_equal(got, co.warp_perspective(src, M, (512, 48), 1))
