@@ -25,11 +25,6 @@ bool finite9(const double* m, int n) {
     return true;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 // Evaluation block width of the reference algorithm (OpenCV WarpPerspectiveInvoker, BLOCK_SZ = 32):
 // bh0 = min(16, h); bw0 = min(1024 / bh0, w).  Values depend on bw0 only.
 int block_width(int dst_w, int dst_h) {
@@ -39,10 +34,6 @@ int block_width(int dst_w, int dst_h) {
 }
 
 }  // namespace
-
-#ifdef BEVWARP_TIMING
-namespace bevwarp { hipError_t debug_read_phases(unsigned long long* out16, int reset); }
-#endif
 
 extern "C" {
 
@@ -140,34 +131,15 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     a.dst_w = dst_w;
     a.m_stride = m_count == 1 ? 0 : 9;
     a.bw0 = block_width(dst_w, dst_h);
-    // tile = tile_width x tile_h destination pixels per workgroup; the source box of a tile must fit
-    // lds_bytes or the tile is redone in 16-row bands (tunable for experiments through the environment)
-    // two kernels: warp_tiles stages source tiles in LDS; warp_gather samples global memory directly and needs
-    // every tile inside one evaluation block.  BEVWARP_MODE: 0 = pick (default), 1 = staged, 2 = gather.
-    const int mode = env_int("BEVWARP_MODE", 0);
-    // warp_gather needs a lane's pixels inside one evaluation block; warp_wave (mode 3) the whole 16-lane-wide tile
-    const bool lane_ok = (a.bw0 % pixels_per_lane_of(dtype) == 0) || (a.bw0 >= dst_w);
-    const bool tile_ok = (a.bw0 % tile_width(dtype, 2) == 0) || (a.bw0 >= dst_w);
-    a.gather = (mode == 3 && tile_ok) ? 2 : ((lane_ok && (mode == 2 || (mode == 0 && env_int("BEVWARP_DEFAULT_GATHER", 1)))) ? 1 : 0);
-    if (po) {  // planar output lives in warp_gather only
-        if (!lane_ok) return BEVWARP_ERR_UNSUPPORTED;
-        a.gather = 1;
-    }
-    const int tw = tile_width(dtype, a.gather);
-    if (a.gather) {
-        // rows per workgroup: 16 (four per wave) is the floor; 8-bit pixels are ALU-bound enough for the per-wave set-up
-        // to show, so they take 32-row tiles when the launch still has >= 4096 workgroups (16 per CU: footprints
-        // with large outside regions make workgroups uneven, and 64-row tiles lose more to the tail than they save)
-        int dflt = band_rows(a.gather) * 4;
-        if (a.gather == 1 && dtype == BEVWARP_U8) {
-            const int64_t per_row_of_tiles = (int64_t)batch * ((dst_w + tw - 1) / tw);
-            if (per_row_of_tiles * ((dst_h + 2 * dflt - 1) / (2 * dflt)) >= 4096) dflt *= 2;
-        }
-        a.tile_h = env_int("BEVWARP_GATHER_TILE_H", dflt);
-        if (a.tile_h < band_rows(a.gather) || a.tile_h > 1024 || a.tile_h % band_rows(a.gather)) a.tile_h = dflt;
-    } else {
-        a.tile_h = env_int("BEVWARP_TILE_H", dtype == BEVWARP_U8 ? 32 : 16);
-        if (a.tile_h < 16 || a.tile_h > kMaxTileH || a.tile_h % band_rows(0)) a.tile_h = 16;
+    // tile = tile_width x tile_h destination pixels per workgroup.  16 rows (four per wave) is the floor; 8-bit pixels are
+    // ALU-bound enough for the per-wave set-up to show, so they take 32-row tiles when the launch still has >= 4096
+    // workgroups (16 per CU: footprints with large outside regions make workgroups uneven, and 64-row tiles lose more to
+    // the tail than they save)
+    const int tw = tile_width(dtype);
+    a.tile_h = rows_per_pass() * 4;
+    if (dtype == BEVWARP_U8) {
+        const int64_t per_row_of_tiles = (int64_t)batch * ((dst_w + tw - 1) / tw);
+        if (per_row_of_tiles * ((dst_h + 2 * a.tile_h - 1) / (2 * a.tile_h)) >= 4096) a.tile_h *= 2;
     }
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
@@ -183,24 +155,9 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     a.tpf_magic = magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
     a.tx_magic = magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
     a.bw0_magic = magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
-    if (a.gather == 2) {  // per-wave slot
-        a.lds_bytes = env_int("BEVWARP_SLOT_BYTES", dtype == BEVWARP_U8 ? 8 * 1024 : 12 * 1024);
-        if (a.lds_bytes < 1024) a.lds_bytes = 1024;
-        if (a.lds_bytes > 15 * 1024) a.lds_bytes = 15 * 1024;
-    } else {
-        a.lds_bytes = env_int("BEVWARP_LDS_BYTES", 32 * 1024);
-        if (a.lds_bytes < 0) a.lds_bytes = 0;
-        if (a.lds_bytes > 60 * 1024) a.lds_bytes = 60 * 1024;
-    }
-    a.lds_bytes &= ~15;
-
-    // staged loads: u8x3 reads 12-byte groups (4-byte aligned), the other formats 16-byte chunks;
-    // both need the row to end on a 4-pixel boundary so a group never crosses into the next row.
-    const bool u8x3 = dtype == BEVWARP_U8 && channels == 3;
-    const int src_align = (u8x3 && a.gather != 2) ? 4 : 16;
-    a.src_vec_ok = (src_w % 4 == 0 || a.gather == 2) && ((uintptr_t)src % src_align == 0) && (src_row_stride % src_align == 0) &&
-                   (src_frame_stride % src_align == 0) && a.lds_bytes > 0 && !env_int("BEVWARP_NO_LDS", 0);
-    const int dst_align = (u8x3 && !po) ? 4 : 16;
+    // wide stores: one lane writes its 4 consecutive 8-bit pixels (4 C bytes; 12-byte stores need 4-byte alignment) or 16
+    // bytes of float data
+    const int dst_align = (dtype == BEVWARP_U8 && !po) ? (channels == 4 ? 16 : (channels == 2 ? 8 : 4)) : 16;
     a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);
     if (po) {
         a.planar = 1;
@@ -281,9 +238,5 @@ int bevwarp_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb,
     const hipError_t e = bevwarp::launch_rbox_iou(a, na, a_stride, b, nb, b_stride, out, dtype, (hipStream_t)stream);
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
-
-#ifdef BEVWARP_TIMING
-int bevwarp_debug_phases(unsigned long long* out16, int reset) { return (int)bevwarp::debug_read_phases(out16, reset); }
-#endif
 
 }  // extern "C"

@@ -20,7 +20,8 @@ struct H9 {
 };
 
 template <typename T, int DIM>
-__global__ __launch_bounds__(256) void project_points_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n, const H9 H) {
+// (`out` may be `in`: every lane reads its own point before it writes it, and neither pointer is __restrict__)
+__global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out, int64_t n, const H9 H) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double x, y, w = 1.0;
@@ -158,8 +159,8 @@ __device__ __forceinline__ uint32_t composite_byte(uint32_t bg, uint32_t fg, uin
     const double v = rint((double)fg * a + (double)bg * (1.0 - a));
     return (uint32_t)(v > 255.0 ? 255.0 : v);
 }
-__global__ __launch_bounds__(256) void composite_kernel(const uint8_t* __restrict__ bg, const uint8_t* __restrict__ fg, const uint8_t* __restrict__ mask,
-                                                        uint8_t* __restrict__ out, int64_t n, int vec_ok) {
+// (`out` may be `bg` or `fg`: a lane reads its 16 bytes of each input before it writes them; no pointer is __restrict__)
+__global__ __launch_bounds__(256) void composite_kernel(const uint8_t* bg, const uint8_t* fg, const uint8_t* mask, uint8_t* out, int64_t n, int vec_ok) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (i0 >= n) return;
     if (vec_ok && i0 + 16 <= n) {
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const uint8_t* __restric
 
 hipError_t launch_composite(const uint8_t* bg, const uint8_t* fg, const uint8_t* mask, uint8_t* out, int64_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    (void)hipGetLastError();  // a stale error left by the host framework is not this call's
     const int vec_ok = (((uintptr_t)bg | (uintptr_t)fg | (uintptr_t)mask | (uintptr_t)out) & 15) == 0;
     const int64_t lanes = (n + 15) / 16;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, bg, fg, mask, out, n, vec_ok);
@@ -190,6 +192,7 @@ hipError_t launch_composite(const uint8_t* bg, const uint8_t* fg, const uint8_t*
 
 hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, const double* H, int dtype, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
     H9 h;
     for (int i = 0; i < 9; i++) h.h[i] = H[i];
     const int block = 256;
@@ -212,6 +215,7 @@ hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, 
 hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype,
                            hipStream_t stream) {
     if (na == 0 || nb == 0) return hipSuccess;
+    (void)hipGetLastError();
     const dim3 block(256), grid((nb + 255) / 256, na);
     if (dtype == 2)
         hipLaunchKernelGGL(rbox_iou_kernel<double>, grid, block, 0, stream, (const double*)a, na, a_stride, (const double*)b, nb, b_stride, (double*)out);

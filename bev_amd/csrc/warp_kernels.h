@@ -7,7 +7,6 @@ namespace bevwarp {
 
 constexpr int kNearest = 0;
 constexpr int kLinear = 1;
-constexpr int kMaxTileH = 64;  // rows of one workgroup's tile (multiple of 16)
 
 struct WarpArgs {
     const uint8_t* src;
@@ -21,12 +20,9 @@ struct WarpArgs {
     int m_stride;                // 9 (one matrix per frame) or 0 (shared)
     int bw0;                     // evaluation block width of the reference algorithm
     int tiles_x, tiles_per_frame;
-    int tile_h;                  // 16, 32, 48 or 64 rows per workgroup
+    int tile_h;                  // rows per workgroup (a multiple of the 4 rows one pass of its waves covers)
     int chunk;                   // items per XCD: grid = 8 * chunk
-    int lds_bytes;               // dynamic LDS given to the staged region
-    int src_vec_ok;              // source layout admits the aligned staging loads
     int dst_vec_ok;              // destination layout admits the wide stores
-    int gather;                  // 1 = warp_gather (no LDS staging), 0 = warp_tiles
     float bval_f[4];
     uint8_t bval_u8[4];
     // planar float output of 8-bit warps (bevwarp_warp_planar): dst[c][y][x] = float(pixel) * pscale[c] + pbias[c]
@@ -35,9 +31,8 @@ struct WarpArgs {
     float pscale[4], pbias[4];
 };
 
-int tile_width(int dtype, int kernel);  // kernel: 0 = warp_tiles, 1 = warp_gather, 2 = warp_wave
-int band_rows(int kernel);
-int pixels_per_lane_of(int dtype);
+int tile_width(int dtype);   // destination pixels per row segment of one wave: 256 (8-bit) / 128 (float)
+int rows_per_pass();         // rows one pass of a workgroup's waves covers
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);

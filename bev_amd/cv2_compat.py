@@ -1,0 +1,86 @@
+"""A `cv2`-shaped module over the MI355X path: the handful of OpenCV entry points the reference's warp path calls, with
+OpenCV's argument order, defaults, flag values and return shapes, so that an integrator can write
+
+    import bev_amd.cv2_compat as cv2          # or: sys.modules["cv2"] = bev_amd.cv2_compat, before `import bev`
+
+and leave /root/reference/vis_homo.py:89-91, bev/homo.py:36 and bev/tool/compo.py:38,46,47 untouched.
+
+    cv2.warpPerspective(img, H, (w, h)[, dst, flags, borderMode, borderValue])   vis_homo.py:89,91; compo.py:38,46,47
+    cv2.findHomography(pts_src, pts_tgt[, method]) -> (H, mask)                  bev/homo.py:36
+    cv2.perspectiveTransform(pts (N,1,2), H) -> (N,1,2)                          (OpenCV's name for pts_world_bev, bev/rbox.py:136-151)
+    cv2.resize(img, (w, h))                                                      vis_homo.py:90 (see the note on resize)
+    cv2.invert(M) -> (retval, M_inv)                                             the 3x3 step inside warpPerspective
+
+Pixel work runs on the GPU through libbevwarp.so (no CPU fallback); numpy images go up and come back per call, which is
+what the cv2 call shape implies -- keep frames resident and use bev_amd.warp.warp_perspective / bev_amd.pipeline for
+throughput.  Everything OpenCV offers beyond this list is deliberately absent: an AttributeError names what a caller
+still needs from a real cv2.
+"""
+import numpy as np
+
+from . import warp as _warp
+from .homo import homo_from_pts as _homo_from_pts
+from .rbox import pts_world_bev as _pts_world_bev
+
+__version__ = "bev_amd.cv2_compat"
+
+# flag values of OpenCV 4.x
+INTER_NEAREST = 0
+INTER_LINEAR = 1
+WARP_INVERSE_MAP = 16
+BORDER_CONSTANT = 0
+DECOMP_LU = 0
+RANSAC, LMEDS, RHO = 8, 4, 16
+
+
+def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0):
+    """uint8 / float32 images of 1-4 channels; INTER_LINEAR or INTER_NEAREST, optionally | WARP_INVERSE_MAP;
+    BORDER_CONSTANT with cv::Scalar border semantics.  Bit-exact with the classic fixed-point algorithm
+    (oracle/warp_oracle.c states which OpenCV code path that is)."""
+    return _warp.warpPerspective(src, M, dsize, dst=dst, flags=flags, borderMode=borderMode, borderValue=borderValue)
+
+
+def findHomography(srcPoints, dstPoints, method=0, ransacReprojThreshold=3.0, mask=None, maxIters=2000, confidence=0.995):
+    """Least-squares homography (method 0, the only one the reference uses): returns (H, mask) with H[2, 2] = 1 and an
+    all-ones (N, 1) uint8 mask like OpenCV.  Points may be (N, 2) or (N, 1, 2)."""
+    if method != 0:
+        raise NotImplementedError("findHomography: only method=0 (least squares over all points) is implemented")
+    a = np.asarray(srcPoints, dtype=np.float64).reshape(-1, 2)
+    b = np.asarray(dstPoints, dtype=np.float64).reshape(-1, 2)
+    H = _homo_from_pts(a, b)
+    return H, np.ones((len(a), 1), dtype=np.uint8)
+
+
+def perspectiveTransform(src, m):
+    """(N, 1, 2) or (N, 2) points through the 3x3 m; same shape and dtype back (float32 / float64)."""
+    pts = np.asarray(src)
+    if pts.dtype not in (np.float32, np.float64):
+        raise TypeError("perspectiveTransform: points must be float32 or float64")
+    flat = pts.reshape(-1, 2).astype(np.float64)
+    out = _pts_world_bev(flat, np.asarray(m, dtype=np.float64))
+    return out.astype(pts.dtype).reshape(pts.shape)
+
+
+def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
+    """Bilinear / nearest resize THROUGH THE WARP KERNEL with the pixel-centre mapping cv2.resize uses
+    (x_src = (x_dst + 0.5) * w_src / w_dst - 0.5).  Not bit-identical to cv2.resize: the warp quantises sample positions to
+    1/32 px and blends with a constant border, cv2.resize uses 11-bit coefficients and replicates the edge -- interior
+    pixels agree to +-1 LSB, the outermost half pixel differs.  For the reference's "small" branch (vis_homo.py:90-91) prefer
+    bev_amd.warp.warp_perspective_resized, which folds the resize into the homography and never materialises the image."""
+    img = np.asarray(src)
+    h, w = img.shape[:2]
+    if dsize is None or tuple(dsize) == (0, 0):
+        dsize = (int(round(w * fx)), int(round(h * fy)))
+    S = _warp.resize_matrix((w, h), dsize, align_corners=False)
+    return _warp.warpPerspective(img, S, dsize, dst=dst, flags=interpolation)
+
+
+def invert(src, flags=DECOMP_LU):
+    """3x3 float64 inverse in OpenCV's closed-form evaluation order; (retval, inverse) with retval 0.0 and a zero matrix
+    for a singular input."""
+    M = np.asarray(src, dtype=np.float64)
+    if M.shape != (3, 3):
+        raise NotImplementedError("invert: only 3x3 matrices (the homographies of the warp path)")
+    inv = _warp.invert_homography(M)
+    ok = bool(np.any(inv != 0))
+    return (1.0 if ok else 0.0), inv

@@ -8,7 +8,11 @@ import torch
 
 class GraphedStep:
     """Capture `fn()` (which must only touch preallocated device tensors and launch on the current stream) once;
-    `replay()` re-issues all of its launches as one graph launch."""
+    `replay()` re-issues all of its launches as one graph launch.
+
+    Homographies: a captured launch replays the ADDRESS of its matrix tensor.  Pass `M_inv_device` tensors the caller
+    keeps alive, or numpy matrices that the warm-up calls have already made resident -- `bev_amd.warp.device_inverse` pins
+    every cached entry it hands out during capture and raises on a cache miss instead of uploading inside the capture."""
 
     def __init__(self, fn, warmup=3):
         self._graph = torch.cuda.CUDAGraph()

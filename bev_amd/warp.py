@@ -9,6 +9,7 @@ host with OpenCV's closed form and the inverse is cached on the device (calibrat
 camera).  All pixel work happens in bev_amd/csrc (HIP, gfx950) through the C ABI; nothing here
 falls back to the CPU.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -34,23 +35,70 @@ def invert_homography(M):
     return out
 
 
-_minv_cache = {}
+_MINV_CACHE_MAX = 256
+_minv_cache = collections.OrderedDict()  # (matrix bytes, device, inverse_given) -> device tensor, least recently used first
+_minv_pinned = {}                        # entries whose address a hipGraph capture has seen: never evicted
 
 
 def device_inverse(M, device, inverse_given=False):
-    """(n, 3, 3) float64 device tensor of inverse matrices for forward matrices M (cached by value)."""
+    """(n, 3, 3) float64 device tensor of inverse matrices for forward matrices M (cached by value).
+
+    Lifetime rules (launches only ever receive the tensor's raw address): every use records the current stream on the
+    tensor, so an evicted entry's memory is not handed out again before the launches that read it have run; an entry
+    that is looked up while the current stream is being captured into a graph is pinned for the life of the process
+    (the graph replays its address), and a cache MISS during capture raises -- upload the matrices before capturing
+    (or pass `M_inv_device`, which the caller owns)."""
     if isinstance(M, torch.Tensor) and M.is_cuda and inverse_given:
         return M.to(torch.float64).reshape(-1, 3, 3).contiguous()
+    device = torch.device(device)
     Mh = np.ascontiguousarray(M.detach().cpu().numpy() if isinstance(M, torch.Tensor) else M, dtype=np.float64).reshape(-1, 3, 3)
     key = (Mh.tobytes(), str(device), bool(inverse_given))
+    capturing = device.type == "cuda" and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    hit = _minv_pinned.get(key)
+    if hit is not None:
+        return hit
     hit = _minv_cache.get(key)
     if hit is None:
-        if len(_minv_cache) > 256:
-            _minv_cache.clear()
+        if capturing:
+            raise RuntimeError("device_inverse: homography not resident while a graph is being captured; call the step once "
+                               "before capturing, or pass M_inv_device")
         inv = Mh if inverse_given else invert_homography(Mh)
         hit = torch.from_numpy(inv).to(device)
         _minv_cache[key] = hit
+        while len(_minv_cache) > _MINV_CACHE_MAX:
+            _minv_cache.popitem(last=False)  # (safe: every use recorded its stream, see below)
+    else:
+        _minv_cache.move_to_end(key)
+    if capturing:
+        _minv_pinned[key] = _minv_cache.pop(key)
+    elif hit.is_cuda:
+        hit.record_stream(torch.cuda.current_stream(hit.device))
     return hit
+
+
+def _check_minv(M_inv_device, device, B):
+    """A caller-supplied matrix tensor goes to the kernel as a raw address: it must be exactly what the ABI reads."""
+    t = M_inv_device
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or not t.is_contiguous() or t.device != device:
+        raise ValueError("M_inv_device must be a contiguous float64 tensor on %s" % (device,))
+    if t.dim() < 2 or tuple(t.shape[-2:]) != (3, 3) or t.numel() % 9:
+        raise ValueError("M_inv_device must be (n, 3, 3), got %s" % (tuple(t.shape),))
+    n_m = t.numel() // 9
+    if n_m not in (1, B):
+        raise ValueError("got %d homographies for a batch of %d" % (n_m, B))
+    return n_m
+
+
+def _check_out(out, dtype, device, numel):
+    """A caller-supplied destination is written through its raw address with the SOURCE's element size."""
+    if not isinstance(out, torch.Tensor) or out.dtype != dtype or out.device != device or out.numel() != numel:
+        raise ValueError("out must be a %s tensor of %d elements on %s" % (dtype, numel, device))
+
+
+def _border(border_value, C):
+    if border_value is None:
+        return None
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(border_value, dtype=np.float64), (C,)))
 
 
 def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=None, M_inv_device=None):
@@ -85,18 +133,15 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     esz = s4.element_size()
     if M_inv_device is None:
         M_inv_device = device_inverse(M, s4.device, inverse_given=bool(int(flags) & WARP_INVERSE_MAP))
-    n_m = M_inv_device.shape[0]
-    if n_m not in (1, B):
-        raise ValueError("got %d homographies for a batch of %d" % (n_m, B))
+    n_m = _check_minv(M_inv_device, s4.device, B)
     if out is None:
         d4 = torch.empty((B, dh, dw, C), dtype=s4.dtype, device=s4.device)
     else:
+        _check_out(out, s4.dtype, s4.device, B * dh * dw * C)
         d4 = out.reshape(B, dh, dw, C)
         if d4.data_ptr() != out.data_ptr() or d4.stride(3) != 1 or d4.stride(2) != C:
             raise ValueError("out must be a contiguous-row channels-last tensor")
-    bv = None
-    if border_value is not None:
-        bv = np.ascontiguousarray(np.broadcast_to(np.asarray(border_value, dtype=np.float64), (C,)))
+    bv = _border(border_value, C)
     stream = torch.cuda.current_stream(s4.device).cuda_stream
     with torch.cuda.device(s4.device):
         st = _lib.load().bevwarp_warp(
@@ -142,14 +187,13 @@ def warp_to_planar(src, M, dsize, scale=1.0 / 255.0, bias=0.0, flags=INTER_LINEA
     dw, dh = int(dsize[0]), int(dsize[1])
     if M_inv_device is None:
         M_inv_device = device_inverse(M, s4.device, inverse_given=bool(int(flags) & WARP_INVERSE_MAP))
-    n_m = M_inv_device.shape[0]
-    if n_m not in (1, B):
-        raise ValueError("got %d homographies for a batch of %d" % (n_m, B))
+    n_m = _check_minv(M_inv_device, s4.device, B)
     if out is None:
         d4 = torch.empty((B, C, dh, dw), dtype=torch.float32, device=s4.device)
     else:
+        _check_out(out, torch.float32, s4.device, B * C * dh * dw)
         d4 = out.reshape(B, C, dh, dw)
-        if d4.data_ptr() != out.data_ptr() or d4.dtype != torch.float32 or d4.stride(3) != 1:
+        if d4.data_ptr() != out.data_ptr() or d4.stride(3) != 1:
             raise ValueError("out must be a float32 (B, C, h, w) tensor with contiguous rows")
     def per_channel(v):
         return np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (C,)))
@@ -183,6 +227,15 @@ def footprint(src_hw, M, dsize, batch=None, flags=INTER_LINEAR, device="cuda"):
     return touched.reshape(n, -1).sum(dim=1, dtype=torch.int64), touched
 
 
+def scalar_border(borderValue, channels):
+    """cv2 turns `borderValue` into a cv::Scalar: a bare number v means (v, 0, 0, 0) -- channel 0 only -- and a sequence
+    fills the leading channels, the rest stay 0."""
+    v = np.atleast_1d(np.asarray(borderValue, dtype=np.float64)).ravel()[:4]
+    out = np.zeros(channels, dtype=np.float64)
+    out[:min(len(v), channels)] = v[:channels]
+    return out
+
+
 def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=0, device="cuda"):
     """cv2.warpPerspective call shape for numpy images: uploads, warps on the GPU, downloads.
     (The per-frame PCIe round trip dominates here; batch frames with warp_perspective for throughput.)"""
@@ -192,9 +245,7 @@ def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORD
     if img.dtype not in (np.uint8, np.float32):
         raise ValueError("unsupported dtype %s (uint8 / float32)" % img.dtype)
     t = torch.from_numpy(np.ascontiguousarray(img)).to(device)
-    bv = borderValue
-    if np.ndim(bv) > 0:
-        bv = np.asarray(bv, dtype=np.float64).ravel()[:(1 if img.ndim == 2 else img.shape[2])]
+    bv = scalar_border(borderValue, 1 if img.ndim == 2 else img.shape[2])
     res = warp_perspective(t, np.asarray(M, dtype=np.float64), dsize, flags=flags, border_value=bv).cpu().numpy()
     if dst is not None:
         dst[...] = res

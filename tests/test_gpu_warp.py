@@ -223,15 +223,15 @@ def test_config4_single_4k_frame(W):
     check(run_gpu(W, f, Mb, (dw, dh), 1), co.warp_perspective(f, Mb, (dw, dh), nthreads=8))
 
 
-# ---- the three kernels behind the same ABI (BEVWARP_MODE: 1 = LDS tiles per workgroup, 2 = direct gather,
-# ---- 3 = wave-private LDS tiles by LDS-DMA) must all reproduce the oracle; the default picks one of them.
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+# ---- every tile shape of the one kernel: ragged last tiles (destination width not a multiple of 256 / 128), fewer than
+# ---- 16 rows (evaluation blocks wider than 64 px, lanes straddling them), destinations whose layout rules out the wide
+# ---- stores, tiny frames -- all through the row-classified path, all bit-exact with the oracle.
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("interp", [0, 1])
-def test_every_kernel_variant_matches_oracle(W, monkeypatch, mode, dtype, interp):
-    monkeypatch.setenv("BEVWARP_MODE", mode)
+def test_every_tile_shape_matches_oracle(W, dtype, interp):
     cases = [("keystone", 1920, 1080, 1024, 1024), ("brno", 1280, 720, 512, 512), ("brno", 192, 108, 37, 53),
-             ("keystone", 856, 480, 300, 200), ("keystone", 100, 60, 300, 9)]
+             ("keystone", 856, 480, 300, 200), ("keystone", 100, 60, 300, 9), ("keystone", 640, 360, 1000, 3),
+             ("brno", 640, 360, 333, 7), ("keystone", 640, 360, 257, 40), ("brno", 640, 360, 129, 33)]
     for kind, sw, sh, dw, dh in cases:
         M = (wl.synth_brno_H if kind == "brno" else wl.keystone_H)(sw, sh, dw, dh)
         src = wl.frame(2, sh, sw, dtype)
@@ -246,3 +246,9 @@ def test_every_kernel_variant_matches_oracle(W, monkeypatch, mode, dtype, interp
     Mv = wl.keystone_H(576, 300, 128, 96)
     got = W.warp_perspective(view, Mv, (128, 96), flags=interp).cpu().numpy()
     check(got, co.warp_perspective(np.ascontiguousarray(view.cpu().numpy()), Mv, (128, 96), interp))
+    # odd destination widths: rows start at byte offsets that rule out the wide stores
+    for c in (1, 2, 3):
+        src = wl.frame(5, 200, 320, dtype, c)
+        Mo = wl.synth_brno_H(320, 200, 301, 41)
+        got = W.warp_perspective(torch.from_numpy(src).cuda(), Mo, (301, 41), flags=interp).cpu().numpy()
+        check(got, co.warp_perspective(src, Mo, (301, 41), interp))
