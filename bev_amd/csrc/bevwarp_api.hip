@@ -35,6 +35,11 @@ int block_width(int dst_w, int dst_h) {
 
 }  // namespace
 
+#ifdef BEVWARP_CLOCK
+namespace bevwarp { hipError_t debug_read_clock(unsigned long long* out4, int reset); }
+extern "C" int bevwarp_debug_clock(unsigned long long* out4, int reset) { return (int)bevwarp::debug_read_clock(out4, reset); }
+#endif
+
 extern "C" {
 
 int bevwarp_version(void) { return BEVWARP_ABI_VERSION; }
@@ -141,6 +146,9 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
         const int64_t per_row_of_tiles = (int64_t)batch * ((dst_w + tw - 1) / tw);
         if (per_row_of_tiles * ((dst_h + 2 * a.tile_h - 1) / (2 * a.tile_h)) >= 4096) a.tile_h *= 2;
     }
+#ifdef BEVWARP_TILE_H  // experiments only
+    a.tile_h = BEVWARP_TILE_H;
+#endif
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
     a.tiles_per_frame = a.tiles_x * tiles_y;
@@ -159,6 +167,7 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // bytes of float data
     const int dst_align = (dtype == BEVWARP_U8 && !po) ? (channels == 4 ? 16 : (channels == 2 ? 8 : 4)) : 16;
     a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);
+    a.src_stage_ok = ((uintptr_t)src % 16 == 0) && (src_row_stride % 16 == 0) && (src_frame_stride % 16 == 0);
     if (po) {
         a.planar = 1;
         a.dst_ps = po->plane_stride;

@@ -23,6 +23,7 @@ struct WarpArgs {
     int tile_h;                  // rows per workgroup (a multiple of the 4 rows one pass of its waves covers)
     int chunk;                   // items per XCD: grid = 8 * chunk
     int dst_vec_ok;              // destination layout admits the wide stores
+    int src_stage_ok;            // source rows start on 16-byte boundaries: tiles may be staged in LDS by 16-byte LDS-DMA
     float bval_f[4];
     uint8_t bval_u8[4];
     // planar float output of 8-bit warps (bevwarp_warp_planar): dst[c][y][x] = float(pixel) * pscale[c] + pbias[c]

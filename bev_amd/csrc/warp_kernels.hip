@@ -298,10 +298,40 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef BEVWARP_U8LIN_WAVES
 #define BEVWARP_U8LIN_WAVES 3
 #endif
+#ifndef BEVWARP_STAGED_WAVES
+#define BEVWARP_STAGED_WAVES 4
+#endif
+// MODE: how an instantiation feeds its taps.  A tile is cut into groups of 4 rows (one per wave); a test of the group's four
+// corner pixels says whether the group can be STAGED (every pixel samples inside the frame, W of one sign, the source box
+// fits the LDS ring).
+//   kGather  every row through the software-pipelined gather loop (taps of the next row in flight in VGPRs: 3 waves per
+//            SIMD for 8-bit RGB bilinear).  Used when the source layout rules staging out.
+//   kStaged  the staged groups of a tile from LDS (no taps in flight in registers: 4 waves per SIMD, which is what the
+//            ALU-bound 8-bit bilinear formats need), then the tile's other rows -- the frame's edge crosses them, or their
+//            boxes do not fit -- through the same row classes one row at a time, within the same register budget.
+enum { kGather = 0, kStaged = 1 };
+// Diagnostic build only (-DBEVWARP_CLOCK, tools/clock.py): wave 0 of every workgroup adds the shader-clock ticks
+// (s_memtime) and the 100 MHz reference ticks (s_memrealtime) it lived for; their ratio is the clock the chip held.
+#ifdef BEVWARP_CLOCK
+__device__ unsigned long long g_clk[16];  // [0..2] life ticks / reference ticks / workgroups, [4..] ticks per phase of the row loop
+#define STAMP(i)                                                           \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        phase_[i] += now_ - stamp_;                                        \
+        stamp_ = now_;                                                     \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+template <typename T, int C, int INTERP, int MODE>
+constexpr int waves_per_simd() {
+    return MODE == kStaged ? BEVWARP_STAGED_WAVES : ((sizeof(T) == 1 && C >= 3 && INTERP == kLinear) ? BEVWARP_U8LIN_WAVES : 4);
+}
+// formats with a staged kernel (bilinear 8-bit pixels: the ones bound by vector-ALU issue)
 template <typename T, int C, int INTERP>
-constexpr int waves_per_simd() { return (sizeof(T) == 1 && C >= 3 && INTERP == kLinear) ? BEVWARP_U8LIN_WAVES : 4; }
-template <typename T, int C, int INTERP, bool RS4, bool PLANAR>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, C, INTERP>(), 8))) void warp_rows(const WarpArgs a) {
+constexpr bool has_staged_kernel() { return sizeof(T) == 1 && INTERP == kLinear; }
+template <typename T, int C, int INTERP, bool RS4, bool PLANAR, int MODE>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, C, INTERP, MODE>(), 8))) void warp_rows(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int TW = 64 * PPL;
     constexpr int PBs = (int)sizeof(T) * C;                      // source bytes per pixel
@@ -320,7 +350,32 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     static_assert(!PLANAR || sizeof(T) == 1, "planar output is the 8-bit -> float32 egress path");
     static_assert(!RS4 || kAligned, "RS4 only qualifies the aligned-window variant");
     __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves][TRW];
+    // Staged tiles (8-bit pixels): the source box of every 4-row group of the tile goes to LDS by coalesced 16-byte
+    // LDS-DMA row loads, two groups in flight; taps are dword windows read from LDS (+ funnel shift when a pixel is not a
+    // whole number of dwords).  kPitch covers a TW-pixel segment magnified up to 1.9 x; a tile whose groups need more
+    // than kStageRows source rows or kPitch bytes per row takes the gather path below.
+    constexpr bool kStage = MODE == kStaged;
+    static_assert(!kStage || has_staged_kernel<T, C, INTERP>(), "no staged kernel for this format");
+    constexpr int kStageRows = 10;
+    constexpr int kPitch = ((TW * PBs * 19 / 10 + 48) + 255) & ~255;
+    constexpr int kBufBytes = kStageRows * kPitch;
+    constexpr bool kFunnel = (PBs % 4) != 0;
+    constexpr int NEED = LOADB / 4;                 // dwords of a tap row the blend takes, starting AT the left tap
+    constexpr int NDW = kFunnel ? NEED + 1 : NEED;  // dwords read per tap row (the aligned window around them)
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStage ? 2 * kBufBytes : 16];
 
+#ifdef BEVWARP_CLOCK
+    struct ClockStamp {
+        unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        __device__ ~ClockStamp() {
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - t0);
+                atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+                atomicAdd(&g_clk[2], 1ull);
+            }
+        }
+    } clock_stamp;
+#endif
     // block -> (frame, tile): one XCD (blockIdx & 7) works on one contiguous run of items
     const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
     if (item >= (uint32_t)a.total_tiles) return;
@@ -399,9 +454,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     //   FAST      S0 = byte offset of the tap window, S1 / S2 = low dwords of tX / tY (fx, fy in bits 27..31)
     //   others    S0 = 0 (the dummy load), S1 / S2 = integer coordinates X, Y
     int out_side = 0;  // set for an OUT row: which frame edge the segment lies beyond, and the sign of W
-    auto coords_s = [&](int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) -> int {
-        const double dy = (double)y;
-        const double UX = __builtin_fma(RX, dy, CX), UY = __builtin_fma(RY, dy, CY), UW = __builtin_fma(RW, dy, CW);
+    int end_sxa = 0, end_sya = 0, end_sxb = 0, end_syb = 0;  // source pixel of the two ends of the row coords_s saw last
+    // the fast chain of one row segment: (high, low) dwords of tX / tY for the lane's pixels; returns the tie flag (0 = some
+    // coordinate of this lane lies in a tie window) and the high dwords of the lane's first / last W
+    auto chain_u = [&](double UX, double UY, double UW, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL],
+                       uint32_t& w_first, uint32_t& w_last) __attribute__((always_inline)) -> uint32_t {
         double W[PPL], r[PPL];
         W[0] = UW + cw0;
 #pragma unroll
@@ -420,7 +477,6 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             r[0] = inv * W[1];
             r[1] = inv * W[0];
         }
-        uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL];
         uint32_t tie = 0xffffffffu;
         double Xn = UX + cx0, Yn = UY + cy0;
 #pragma unroll
@@ -434,14 +490,39 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                 Yn += DY;
             }
         }
+        w_first = (uint32_t)__double2hiint(W[0]);
+        w_last = (uint32_t)__double2hiint(W[PPL - 1]);
+        return tie;
+    };
+    auto chain = [&](int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL], uint32_t& w_first, uint32_t& w_last)
+                     __attribute__((always_inline)) -> uint32_t {
+        const double dy = (double)y;  // the row terms at the segment's first pixel
+        return chain_u(__builtin_fma(RX, dy, CX), __builtin_fma(RY, dy, CY), __builtin_fma(RW, dy, CW), hx, lx, hy, ly, w_first, w_last);
+    };
+    // rare: the lane's pixels that lie within 2^-19 of a rounding boundary (or are NaN) take the exact chain
+    auto fix_ties = [&](int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if ((lx[j] & F::kTieMask) == 0 || (ly[j] & F::kTieMask) == 0) {
+                int Xe, Ye;
+                exact_px(y, j, Xe, Ye);
+                int_to_fix<INTERP>(Xe, hx[j], lx[j]);
+                int_to_fix<INTERP>(Ye, hy[j], ly[j]);
+            }
+        }
+    };
+    auto coords_s = [&](int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) -> int {
+        uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], w_first, w_last;
+        const uint32_t tie = chain(y, hx, lx, hy, ly, w_first, w_last);
         // -- classify the segment from its ends (pixel 0 of lane 0, pixel PPL-1 of lane 63), in scalar registers
         auto lane_u32 = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
         const uint32_t hxa = lane_u32(hx[0], 0), hya = lane_u32(hy[0], 0), hxb = lane_u32(hx[PPL - 1], 63), hyb = lane_u32(hy[PPL - 1], 63);
-        const uint32_t wa = lane_u32((uint32_t)__double2hiint(W[0]), 0), wb = lane_u32((uint32_t)__double2hiint(W[PPL - 1]), 63);
+        const uint32_t wa = lane_u32(w_first, 0), wb = lane_u32(w_last, 63);
         const uint32_t ea = (wa >> 20) & 0x7ffu, eb = (wb >> 20) & 0x7ffu;  // 2^-199 .. 2^199: the shared reciprocal is safe
         const bool w_ok = ((wa ^ wb) >> 31) == 0 && ea - 824u <= 398u && eb - 824u <= 398u;
         // source pixel of the two ends (a high dword outside the binade gives |s| >= 2^19: outside every limit below)
         const int sxa = (int)(hxa - kHiBias), sya = (int)(hya - kHiBias), sxb = (int)(hxb - kHiBias), syb = (int)(hyb - kHiBias);
+        end_sxa = sxa, end_sya = sya, end_sxb = sxb, end_syb = syb;
         const bool in = can_fast && w_ok && (uint32_t)(sxa - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(sxb - kM) <= (uint32_t)(sxw_lim - 2 * kM) &&
                         (uint32_t)(sya - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syb - kM) <= (uint32_t)(sy_lim - 2 * kM);
         int cls = kFast;
@@ -453,17 +534,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             cls = !(e_ok && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
             out_side = ((sxa <= -3 && sxb <= -3) ? 1 : (sxa > a.src_w && sxb > a.src_w) ? 2 : (sya <= -3 && syb <= -3) ? 3 : 4) | (int)((wa >> 31) << 3);
         }
-        if (tie == 0 && cls != kSlow) {  // rare: within 2^-19 of a rounding boundary (or NaN) -> the exact chain decides
-#pragma unroll
-            for (int j = 0; j < PPL; j++) {
-                if ((lx[j] & F::kTieMask) == 0 || (ly[j] & F::kTieMask) == 0) {
-                    int Xe, Ye;
-                    exact_px(y, j, Xe, Ye);
-                    int_to_fix<INTERP>(Xe, hx[j], lx[j]);
-                    int_to_fix<INTERP>(Ye, hy[j], ly[j]);
-                }
-            }
-        }
+        if (tie == 0 && cls != kSlow) fix_ties(y, hx, lx, hy, ly);
         if (__builtin_expect(cls == kFast, 1)) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -506,43 +577,57 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     };
 
     uint32_t* wtr = &s_tr[wave][0];
-    // FAST row: blend the taps into the wave's LDS row (pixel 64 j + lane of the segment)
+    // blend one pixel from its taps -- w0 / w1 = the LOADB bytes of the upper / lower tap row starting AT the left tap -- into
+    // the wave's LDS row (pixel 64 j + lane of the segment)
+    auto blend_put = [&](int j, const uint32_t (&w0)[NEED], const uint32_t (&w1)[NEED], uint32_t fx, uint32_t fy) __attribute__((always_inline)) {
+        if constexpr (sizeof(T) == 1) {
+            uint32_t px;
+            if constexpr (INTERP == kNearest)
+                px = C == 4 ? w0[0] : (w0[0] & ((1u << (8 * (C & 3))) - 1u));
+            else if constexpr (C == 3)
+                px = blend_u8_rgb_window(w0[0], w0[1], w1[0], w1[1], fx, fy);
+            else if constexpr (C == 4)
+                px = blend_u8_packed<C>(w0[0], w0[1], w1[0], w1[1], fx, fy);
+            else
+                px = blend_u8_packed<C>(w0[0], w0[0] >> (8 * C), w1[0], w1[0] >> (8 * C), fx, fy);
+            wtr[64 * j + lane] = px;
+        } else {
+            const float* f0 = reinterpret_cast<const float*>(&w0[0]);
+            const float* f1 = reinterpret_cast<const float*>(&w1[0]);
+            float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
+            if (INTERP == kNearest) {
+#pragma unroll
+                for (int k = 0; k < C; k++) wf[k] = f0[k];
+            } else {
+                float w00, w01, w10, w11;
+                weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
+#pragma unroll
+                for (int k = 0; k < C; k++) wf[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+            }
+        }
+    };
+    // FAST row of the gather path: taps from the registers the row's loads filled
     auto finish_s = [&](const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
                         const Bytes<WINB> (&t1)[PPL]) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             const uint32_t fx = S1[j] >> 27, fy = S2[j] >> 27;  // (bilinear only)
-            if constexpr (sizeof(T) == 1) {
-                uint32_t px;
-                if (INTERP == kNearest) {
-                    px = C == 4 ? t0[j].w[0] : (t0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
-                } else if constexpr (kAligned) {
-                    const uint32_t sh0 = S0[j] << 3, sh1 = RS4 ? sh0 : (S0[j] + rs32) << 3;  // funnel-shift amounts (v_alignbit reads bits 4:0)
-                    const uint32_t a0 = __builtin_amdgcn_alignbit(t0[j].w[1], t0[j].w[0], sh0), a1 = __builtin_amdgcn_alignbit(t0[j].w[2], t0[j].w[1], sh0);
-                    const uint32_t b0 = __builtin_amdgcn_alignbit(t1[j].w[1], t1[j].w[0], sh1), b1 = __builtin_amdgcn_alignbit(t1[j].w[2], t1[j].w[1], sh1);
-                    px = blend_u8_rgb_window(a0, a1, b0, b1, fx, fy);
-                } else if constexpr (C == 3) {
-                    px = blend_u8_rgb_window(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
-                } else if constexpr (C == 4) {
-                    px = blend_u8_packed<C>(t0[j].w[0], t0[j].w[1], t1[j].w[0], t1[j].w[1], fx, fy);
-                } else {
-                    px = blend_u8_packed<C>(t0[j].w[0], t0[j].w[0] >> (8 * C), t1[j].w[0], t1[j].w[0] >> (8 * C), fx, fy);
+            uint32_t w0[NEED], w1[NEED];
+            if constexpr (kAligned) {
+                const uint32_t sh0 = S0[j] << 3, sh1 = RS4 ? sh0 : (S0[j] + rs32) << 3;  // funnel-shift amounts (v_alignbit reads bits 4:0)
+#pragma unroll
+                for (int k = 0; k < NEED; k++) {
+                    w0[k] = __builtin_amdgcn_alignbit(t0[j].w[k + 1], t0[j].w[k], sh0);
+                    w1[k] = __builtin_amdgcn_alignbit(t1[j].w[k + 1], t1[j].w[k], sh1);
                 }
-                wtr[64 * j + lane] = px;
             } else {
-                const float* f0 = reinterpret_cast<const float*>(&t0[j]);
-                const float* f1 = reinterpret_cast<const float*>(&t1[j]);
-                float* wf = reinterpret_cast<float*>(wtr) + (64 * j + lane) * C;
-                if (INTERP == kNearest) {
 #pragma unroll
-                    for (int k = 0; k < C; k++) wf[k] = f0[k];
-                } else {
-                    float w00, w01, w10, w11;
-                    weights_f32((int)fx, (int)fy, w00, w01, w10, w11);
-#pragma unroll
-                    for (int k = 0; k < C; k++) wf[k] = blend_f32(f0[k], f0[k + C], f1[k], f1[k + C], w00, w01, w10, w11);
+                for (int k = 0; k < NEED; k++) {
+                    w0[k] = t0[j].w[k];
+                    w1[k] = INTERP == kLinear ? t1[j].w[k] : 0u;
                 }
             }
+            blend_put(j, w0, w1, fx, fy);
         }
     };
     auto put_px = [&](int j, const Pixel<T, C>& v) __attribute__((always_inline)) {
@@ -646,7 +731,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
     };
     auto finish_any = [&](int cls, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
-                          const Bytes<WINB> (&t1)[PPL], uint4 (&out)[NQ]) {
+                          const Bytes<WINB> (&t1)[PPL]) {
         if (__builtin_expect(cls == kFast, 1)) {
             finish_s(S0, S1, S2, t0, t1);
         } else {
@@ -657,7 +742,6 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             else
                 slow_s(y);
         }
-        read_back(out);
     };
 
     // -- stores.  The destination is written once and never read back by this kernel: non-temporal stores keep it from
@@ -722,6 +806,157 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
     };
 
+    // ===== staged tiles ================================================================================
+    // A tile is processed in groups of 4 rows (one per wave).  A group all of whose pixels sample inside the frame (its
+    // corner pixels do, W of one sign: the image of the group is the convex quadrilateral of its corners) and whose
+    // source box fits the LDS ring is STAGED: box(g + 1) streams into LDS while the waves blend group g from LDS.  The
+    // other groups of the tile take the row classes directly.  One barrier per group.
+    uint32_t ok_groups = 0;  // bit g: group g of this tile is staged
+    if constexpr (kStage) {
+        const int ng = (y_last - y0) / kWaves + 1;  // groups of this tile (tile_h / 4 <= 16: one lane per group corner)
+        if (a.src_stage_ok && can_fast && ng <= 16) {
+            // -- corner k of group g in lane 4 g + k: the fast chain for one pixel
+            const int cg = lane >> 2, ck = lane & 3;
+            const bool lane_on = cg < ng;
+            const int cyy = min(y0 + cg * kWaves + ((ck & 2) ? kWaves - 1 : 0), y_last);
+            const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)cyy;
+            const double cW = __builtin_fma(RW, cdy, CW) + m6 * cdx;
+            const double cr = rcp_newton(cW);
+            const double ctx = __builtin_fma(__builtin_fma(RX, cdy, CX) + (m0 * kTwo32) * cdx, cr, F::kMagic);
+            const double cty = __builtin_fma(__builtin_fma(RY, cdy, CY) + (m3 * kTwo32) * cdx, cr, F::kMagic);
+            const int csx = (int)((uint32_t)__double2hiint(ctx) - kHiBias), csy = (int)((uint32_t)__double2hiint(cty) - kHiBias);
+            const uint32_t cwh = (uint32_t)__double2hiint(cW);
+            const bool c_in = (uint32_t)(csx - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(csy - kM) <= (uint32_t)(sy_lim - 2 * kM) &&
+                              ((cwh >> 20) & 0x7ffu) - 824u <= 398u;
+            // min / max over the 4 corners of a group (a quad of lanes): two DPP quad permutes each
+            auto quad_min = [](int v) {
+                v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+                return min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+            };
+            const int gx0 = quad_min(csx) - 1, gx1 = -quad_min(-csx) + 1, gy0 = quad_min(csy) - 1, gy1 = -quad_min(-csy) + 1;  // +-1 px: the exact
+            // chain may move a coordinate by one unit; taps reach one pixel further right / down
+            constexpr int kTapPx = INTERP == kLinear ? 1 : 0;
+            const int g_rows = gy1 + kTapPx + 1 - gy0;                    // source rows gy0 .. gy1 + kTapPx
+            const int g_b0 = (gx0 * PBs) & ~15;                           // first staged byte of a row (16-byte aligned: rows are)
+            const int g_end = (gx1 + kTapPx + 1) * PBs;                   // one byte past the last tap
+            const int g_chunks = (g_end - g_b0 + 15) >> 4;                // 16-byte chunks per row
+            // the last chunk may read up to 15 bytes past its row: it must stay inside the frame's allocation
+            const bool g_tail_ok = (int64_t)(gy1 + kTapPx) * a.src_rs + g_b0 + 16 * (int64_t)g_chunks <= (int64_t)(a.src_h - 1) * a.src_rs + (int64_t)a.src_w * PBs;
+            const bool g_fit = gx0 >= 0 && gy0 >= 0 && g_rows <= kStageRows && g_chunks * 16 <= kPitch && g_tail_ok;
+            // a group can be staged when its four corners sample inside, its box fits, and W has one sign over it; bit g of
+            // ok_groups says so (the four lanes of a quad vote)
+            const uint64_t in_mask = __ballot(lane_on && c_in && g_fit), neg_mask = __ballot(lane_on && (cwh >> 31));
+            for (int g = 0; g < ng; g++) {
+                const uint32_t q_in = (uint32_t)(in_mask >> (4 * g)) & 0xFu, q_neg = (uint32_t)(neg_mask >> (4 * g)) & 0xFu;
+                if (q_in == 0xFu && (q_neg == 0u || q_neg == 0xFu)) ok_groups |= 1u << g;
+            }
+            if (ok_groups != 0) {
+                auto group_i = [](int v, int g) { return __builtin_amdgcn_readlane(v, 4 * g); };
+                auto staged_group = [&](int g) { return g < ng && ((ok_groups >> g) & 1u) != 0; };
+                // -- stage(g): rows of the box are dealt to the waves; lane i moves chunk i (+ 64, ...) of its row
+                auto stage = [&](int g) __attribute__((always_inline)) {
+                    const int r0 = group_i(gy0, g), nr = group_i(g_rows, g), b0 = group_i(g_b0, g), nch = group_i(g_chunks, g);
+                    uint8_t* buf = s_stage + (g & 1) * kBufBytes;
+                    for (int rr = wave; rr < nr; rr += kWaves) {
+                        const uint8_t* grow = frame + (int64_t)(r0 + rr) * a.src_rs + b0 + lane * 16;
+                        uint8_t* lrow = buf + rr * kPitch;
+#pragma unroll
+                        for (int c0 = 0; c0 < kPitch / 16; c0 += 64) {
+                            if (c0 < nch && lane + c0 < nch)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + c0 * 16),
+                                                                 (__attribute__((address_space(3))) void*)(lrow + c0 * 16), 16, 0, 0);
+                        }
+                    }
+                };
+                uint4 out[NQ];
+                int y_prev = -1;
+                if (staged_group(0)) stage(0);
+                for (int g = 0; g < ng; g++) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of box g has landed (and row g - 2 is stored)
+                    __builtin_amdgcn_s_barrier();                      // ... and everybody else's; every wave is done reading box g - 1
+                    if (staged_group(g + 1)) stage(g + 1);
+                    if (y_prev >= 0) read_back(out);  // row g - 1 out of the transposition row (written a whole group ago: no LDS latency)
+                    const int y = y0 + g * kWaves + wave;
+                    const bool on = y <= y_last && staged_group(g);  // (the other groups follow below)
+                    uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
+                    uint32_t raw0[PPL][NDW], raw1[PPL][NDW], o[PPL];
+                    if (on) {
+                        if (chain(y, hx, lx, hy, ly, wf_, wl_) == 0) fix_ties(y, hx, lx, hy, ly);
+                        // LDS byte offset of a pixel's left tap, from the high dwords: (sy - r0) * kPitch + sx * PBs - b0
+                        const uint32_t kL = (uint32_t)(-(group_i(gy0, g) * kPitch) - group_i(g_b0, g)) - 0x380000u * (uint32_t)(kPitch + PBs);
+                        const uint8_t* buf = s_stage + (g & 1) * kBufBytes;
+#pragma unroll
+                        for (int j = 0; j < PPL; j++) {
+                            o[j] = __umul24(hy[j], (uint32_t)kPitch) + (__umul24(hx[j], (uint32_t)PBs) + kL);
+                            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(buf + (kFunnel ? (o[j] & ~3u) : o[j]));
+#pragma unroll
+                            for (int k = 0; k < NDW; k++) {
+                                raw0[j][k] = p0[k];
+                                if (INTERP == kLinear) raw1[j][k] = p0[k + kPitch / 4];
+                            }
+                        }
+                    }
+                    if (y_prev >= 0) store_s(y_prev, out);  // behind the DMA and the tap reads: a whole group of arithmetic to complete
+                    y_prev = -1;
+                    if (on) {
+#pragma unroll
+                        for (int j = 0; j < PPL; j++) {
+                            uint32_t w0[NEED], w1[NEED];
+#pragma unroll
+                            for (int k = 0; k < NEED; k++) {
+                                if constexpr (kFunnel) {
+                                    w0[k] = __builtin_amdgcn_alignbit(raw0[j][k + 1], raw0[j][k], o[j] << 3);
+                                    w1[k] = INTERP == kLinear ? __builtin_amdgcn_alignbit(raw1[j][k + 1], raw1[j][k], o[j] << 3) : 0u;
+                                } else {
+                                    w0[k] = raw0[j][k];
+                                    w1[k] = INTERP == kLinear ? raw1[j][k] : 0u;
+                                }
+                            }
+                            blend_put(j, w0, w1, lx[j] >> 27, ly[j] >> 27);
+                        }
+                        y_prev = y;
+                    }
+                }
+                if (y_prev >= 0) read_back(out);
+                if (y_prev >= 0) store_s(y_prev, out);
+            }
+        }
+    }
+
+    // -- kStaged: the rows of the groups that were not staged, one at a time (load -> wait -> blend -> store).  The waves
+    // of the other workgroups on the CU cover the exposed latency; what matters is that this path fits the staged loop's
+    // register budget.
+    if constexpr (kStage) {
+#ifdef BEVWARP_EXP_NODIRECT
+        return;
+#endif
+        uint32_t A0[PPL], A1[PPL], A2[PPL];
+        Bytes<WINB> u0[PPL], u1[PPL];
+        uint4 out[NQ];
+        int y = y0 + wave;
+        if (y > y_last) return;
+        if (ok_groups == 0) {  // (the probe of the gather loop below: a wave whose rows all lie beyond one frame edge)
+            if (coords_s(y, A0, A1, A2) == kOut && y + kWaves <= y_last) {
+                const int side0 = out_side;
+                const int y_probe = y + ((y_last - y) / kWaves) * kWaves;
+                if (coords_s(y_probe, A0, A1, A2) == kOut && out_side == side0) {
+                    fill_s();
+                    read_back(out);
+                    for (; y <= y_last; y += kWaves) store_s(y, out);
+                    return;
+                }
+            }
+        }
+        for (int g = 0; y <= y_last; g++, y += kWaves) {
+            if ((ok_groups >> g) & 1u) continue;
+            const int cls = coords_s(y, A0, A1, A2);
+            issue_s(cls, A0, u0, u1);
+            finish_any(cls, y, A0, A1, A2, u0, u1);
+            read_back(out);
+            store_s(y, out);
+        }
+        return;
+    }
     // -- the row loop.  Rows of a tile are dealt to its waves round-robin: neighbouring rows share source lines and run
     // at the same time.
     constexpr int RSTEP = kWaves;
@@ -731,6 +966,95 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     uint32_t A0[PPL], A1[PPL], A2[PPL], B0[PPL], B1[PPL], B2[PPL];  // row state: current / next
     Bytes<WINB> u0[PPL], u1[PPL];
     uint4 out[NQ];
+    // -- interior tiles.  When the tile's four corner pixels sample inside the frame by the FAST margin with W of one sign,
+    // the tile maps into the convex quadrilateral of their images: every row is FAST and the loop needs no row classes --
+    // no end-pixel read-out, no scalar decisions, row terms advanced by one addition each.
+    bool tile_in;
+    {
+        const int ck = lane & 3;
+        const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)((ck & 2) ? y_last : y0);
+        const double cW = __builtin_fma(RW, cdy, CW) + m6 * cdx;
+        const double cr = rcp_newton(cW);
+        const double ctx = __builtin_fma(__builtin_fma(RX, cdy, CX) + (m0 * kTwo32) * cdx, cr, F::kMagic);
+        const double cty = __builtin_fma(__builtin_fma(RY, cdy, CY) + (m3 * kTwo32) * cdx, cr, F::kMagic);
+        const int csx = (int)((uint32_t)__double2hiint(ctx) - kHiBias), csy = (int)((uint32_t)__double2hiint(cty) - kHiBias);
+        const uint32_t cwh = (uint32_t)__double2hiint(cW);
+        // (one pixel more than the rows' own margin: the exact chain may move a coordinate by a unit)
+        const bool c_in = (uint32_t)(csx - kM - 1) <= (uint32_t)(sxw_lim - 2 * kM - 2) && (uint32_t)(csy - kM - 1) <= (uint32_t)(sy_lim - 2 * kM - 2) &&
+                          ((cwh >> 20) & 0x7ffu) - 824u <= 398u;
+        const uint32_t in4 = (uint32_t)__ballot(c_in) & 0xFu, neg4 = (uint32_t)__ballot((cwh >> 31) != 0) & 0xFu;
+        tile_in = can_fast && sxw_lim >= 2 * kM + 2 && sy_lim >= 2 * kM + 2 && in4 == 0xFu && (neg4 == 0u || neg4 == 0xFu);
+    }
+    if (tile_in) {
+        double UX = __builtin_fma(RX, (double)yf, CX), UY = __builtin_fma(RY, (double)yf, CY), UW = __builtin_fma(RW, (double)yf, CW);
+        const double SX = uniform_f64(RX * (double)RSTEP), SY = uniform_f64(RY * (double)RSTEP), SW = uniform_f64(RW * (double)RSTEP);
+        // coordinates of the NEXT row of this wave (each call advances the row terms)
+        int y_next = yf;
+        auto coords_f = [&](uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
+            uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
+            if (chain_u(UX, UY, UW, hx, lx, hy, ly, wf_, wl_) == 0) fix_ties(y_next, hx, lx, hy, ly);
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                S0[j] = __umul24(hy[j], rs32) + (__umul24(hx[j], (uint32_t)PBs) + kOff);
+                S1[j] = lx[j];
+                S2[j] = ly[j];
+            }
+            UX += SX;
+            UY += SY;
+            UW += SW;
+            y_next += RSTEP;
+        };
+        // one step: row yf's pixels leave the LDS row, the next row's loads are issued from state C, the row after that
+        // gets its coordinates into state N, row yf is stored, the next row is blended
+        bool more = yf + RSTEP <= y_end;
+        auto step = [&](uint32_t (&C0)[PPL], uint32_t (&C1)[PPL], uint32_t (&C2)[PPL], uint32_t (&N0)[PPL], uint32_t (&N1)[PPL], uint32_t (&N2)[PPL])
+                        __attribute__((always_inline)) {
+            read_back(out);
+            issue_s(kFast, C0, u0, u1);
+            const int y_done = yf;
+            yf += RSTEP;
+            more = yf + RSTEP <= y_end;
+            if (more) coords_f(N0, N1, N2);
+            store_s(y_done, out);
+            finish_s(C0, C1, C2, u0, u1);
+        };
+        coords_f(A0, A1, A2);
+        issue_s(kFast, A0, u0, u1);
+        if (more) coords_f(B0, B1, B2);
+        finish_s(A0, A1, A2, u0, u1);
+        while (more) {  // (two steps per trip: the row states swap roles instead of being copied)
+            step(B0, B1, B2, A0, A1, A2);
+            if (!more) break;
+            step(A0, A1, A2, B0, B1, B2);
+        }
+        read_back(out);
+        store_s(yf, out);
+        return;
+    }
+#ifdef BEVWARP_DIRECT_EDGE
+    {
+        int cls = coords_s(yf, A0, A1, A2);
+        if (cls == kOut && yf + RSTEP <= y_end) {
+            const int side0 = out_side;
+            const int y_probe = yf + ((y_end - yf) / RSTEP) * RSTEP;
+            if (coords_s(y_probe, B0, B1, B2) == kOut && out_side == side0) {
+                fill_s();
+                read_back(out);
+                for (int y = yf; y <= y_end; y += RSTEP) store_s(y, out);
+                return;
+            }
+        }
+        for (;;) {
+            issue_s(cls, A0, u0, u1);
+            finish_any(cls, yf, A0, A1, A2, u0, u1);
+            read_back(out);
+            store_s(yf, out);
+            yf += RSTEP;
+            if (yf > y_end) return;
+            cls = coords_s(yf, A0, A1, A2);
+        }
+    }
+#endif
     int cls_c = coords_s(yf, A0, A1, A2), cls_n = kSlow;
     if (cls_c == kOut && yf + RSTEP <= y_end) {
         // The wave's first row lies beyond a frame edge: probe its last row.  When that one lies beyond the same edge
@@ -747,12 +1071,16 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
     }
     issue_s(cls_c, A0, u0, u1);
-    // Order inside an iteration: next row's loads, THEN the finished row's store, then the arithmetic.  vmcnt retires in
-    // issue order, so a store issued before a row's loads would have to reach L2 before that row's taps can be used;
-    // issued after them it has a whole iteration to complete.
+    // Order inside an iteration: the previous row's pixels out of the LDS row (written an iteration ago: no LDS latency
+    // on the path), the next row's loads, the next-but-one row's coordinates, THEN the previous row's store, then the
+    // blend.  vmcnt retires in issue order, so a store issued before a row's loads would have to reach L2 before that
+    // row's taps can be used; issued after them it has a whole iteration to complete.
     bool more = yf + RSTEP <= y_end;
     if (more) cls_n = coords_s(yf + RSTEP, B0, B1, B2);
-    finish_any(cls_c, yf, A0, A1, A2, u0, u1, out);
+    finish_any(cls_c, yf, A0, A1, A2, u0, u1);
+#ifdef BEVWARP_CLOCK
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime(), phase_[4] = {0, 0, 0, 0};
+#endif
     while (more) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
@@ -761,14 +1089,25 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             A2[j] = B2[j];
         }
         cls_c = cls_n;
+        read_back(out);              // row yf
         issue_s(cls_c, A0, u0, u1);  // row yf + RSTEP
-        store_s(yf, out);            // row yf
+        STAMP(0);
+        const int y_done = yf;
         yf += RSTEP;
         more = yf + RSTEP <= y_end;
         if (more) cls_n = coords_s(yf + RSTEP, B0, B1, B2);  // overlaps with the loads in flight
-        finish_any(cls_c, yf, A0, A1, A2, u0, u1, out);
+        STAMP(1);
+        store_s(y_done, out);
+        STAMP(2);
+        finish_any(cls_c, yf, A0, A1, A2, u0, u1);
+        STAMP(3);
     }
+    read_back(out);
     store_s(yf, out);
+#ifdef BEVWARP_CLOCK
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 4; i++) atomicAdd(&g_clk[4 + i], phase_[i]);
+#endif
 }
 
 // Footprint: mark every in-bounds source pixel any tap would read (measurement aid; exact chain).
@@ -797,22 +1136,35 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
         }
 }
 
-template <typename T, int C, int INTERP>
-void launch_tci(const WarpArgs& a, dim3 grid, hipStream_t stream) {
+template <typename T, int C, int INTERP, int MODE>
+void launch_mode(const WarpArgs& a, dim3 grid, hipStream_t stream) {
     constexpr bool kRgb8Lin = sizeof(T) == 1 && C == 3 && INTERP == kLinear;
     if constexpr (sizeof(T) == 1) {
         if (a.planar) {
             if (kRgb8Lin && a.src_rs % 4 == 0)
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true>), grid, dim3(kWG), 0, stream, a);
+                hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true, MODE>), grid, dim3(kWG), 0, stream, a);
             else
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true>), grid, dim3(kWG), 0, stream, a);
+                hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true, MODE>), grid, dim3(kWG), 0, stream, a);
             return;
         }
     }
     if (kRgb8Lin && a.src_rs % 4 == 0)
-        hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, false>), grid, dim3(kWG), 0, stream, a);
+        hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, false, MODE>), grid, dim3(kWG), 0, stream, a);
     else
-        hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, false>), grid, dim3(kWG), 0, stream, a);
+        hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, false, MODE>), grid, dim3(kWG), 0, stream, a);
+}
+
+template <typename T, int C, int INTERP>
+void launch_tci(const WarpArgs& a, dim3 grid, hipStream_t stream) {
+    if constexpr (has_staged_kernel<T, C, INTERP>()) {
+#ifndef BEVWARP_FORCE_GATHER
+        if (a.src_stage_ok) {
+            launch_mode<T, C, INTERP, kStaged>(a, grid, stream);
+            return;
+        }
+#endif
+    }
+    launch_mode<T, C, INTERP, kGather>(a, grid, stream);
 }
 
 template <typename T>
@@ -835,6 +1187,17 @@ void launch_t(const WarpArgs& a, int channels, int interp, dim3 grid, hipStream_
 }
 
 }  // namespace
+
+#ifdef BEVWARP_CLOCK
+hipError_t debug_read_clock(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_clk), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
+    }
+    return e;
+}
+#endif
 
 int tile_width(int dtype) { return 64 * (dtype == 0 ? pixels_per_lane<uint8_t>() : pixels_per_lane<float>()); }
 int rows_per_pass() { return kWaves; }

@@ -184,3 +184,51 @@ def test_row_strides_of_every_alignment(W, sw):
         view.copy_(torch.from_numpy(src))
         got = W.warp_perspective(view, M, (512, 48)).cpu().numpy()
         np.testing.assert_array_equal(got, co.warp_perspective(src, M, (512, 48), 1))
+
+
+# ---- the staged kernel (two launches: LDS-staged interior tiles, then the gather kernel for the rest) is taken from 256
+# ---- tiles up; batches of small frames reach it at sizes the oracle finishes in seconds.
+def _batch_case(W, dtype_c, sw, sh, dw, dh, B, kind, interp, pad_to=None, border=None):
+    c = dtype_c
+    frames = np.stack([wl.frame(20 + i, sh, sw, np.uint8, c) for i in range(B)])
+    base = (wl.keystone_H if kind == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh) if kind != "identity" else np.eye(3)
+    Ms = np.stack([wl.jitter_H(base, i, px=3.0) for i in range(B)])
+    t = torch.from_numpy(frames).cuda()
+    if pad_to:  # a row-padded view: row stride pad_to * c bytes
+        big = torch.zeros((B, sh, pad_to, c), dtype=torch.uint8, device="cuda")
+        big[:, :, :sw] = t
+        t = big[:, :, :sw]
+    got = W.warp_perspective(t, Ms, (dw, dh), flags=interp, border_value=border).cpu().numpy()
+    for i in range(B):
+        exp = co.warp_perspective(frames[i], Ms[i], (dw, dh), interp, border_value=0 if border is None else border)
+        np.testing.assert_array_equal(got[i], exp, err_msg="frame %d" % i)
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_staged_tiles_all_channel_counts(W, c):
+    _batch_case(W, c, 640, 360, 512, 256, 8, "keystone", 1)            # 8 x 2 x 16 = 256 tiles, all inside the frame
+
+
+def test_staged_tiles_mixed_with_gather_tiles(W):
+    _batch_case(W, 3, 640, 360, 512, 256, 8, "brno", 1)                 # rotated footprint: (almost) nothing can be staged
+    _batch_case(W, 3, 640, 368, 768, 200, 8, "keystone", 1, border=7)  # ragged last group (200 = 12 x 16 + 8), 3 tiles wide
+    _batch_case(W, 3, 1280, 720, 300, 330, 16, "keystone", 1)           # > 1.9 x magnification: boxes exceed the LDS pitch
+    _batch_case(W, 3, 320, 200, 1024, 64, 16, "keystone", 1)            # minification: boxes a few pixels wide
+
+
+def test_staged_tiles_row_padded_source_and_identity(W):
+    _batch_case(W, 3, 636, 360, 512, 256, 8, "keystone", 1, pad_to=640)  # row stride 1920 B, rows 16-byte aligned, width not
+    _batch_case(W, 3, 640, 360, 512, 256, 8, "identity", 1)              # integer coordinates: every pixel on a tie boundary
+    _batch_case(W, 4, 640, 360, 512, 256, 8, "identity", 1)
+
+
+def test_staged_tiles_planar_output(W):
+    B, sw, sh, dw, dh = 8, 640, 360, 512, 256
+    frames = np.stack([wl.frame(40 + i, sh, sw, np.uint8) for i in range(B)])
+    Ms = np.stack([wl.jitter_H(wl.keystone_H(sw, sh, dw, dh), i) for i in range(B)])
+    scale, bias = [1 / 255.0, 0.5, 2.0], [0.0, -1.0, 3.5]
+    got = W.warp_to_planar(torch.from_numpy(frames).cuda(), Ms, (dw, dh), scale=scale, bias=bias).cpu().numpy()
+    for i in range(B):
+        u8 = co.warp_perspective(frames[i], Ms[i], (dw, dh), 1)
+        exp = np.stack([u8[:, :, k].astype(np.float32) * np.float32(scale[k]) + np.float32(bias[k]) for k in range(3)])
+        np.testing.assert_array_equal(got[i], exp)

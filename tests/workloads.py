@@ -33,6 +33,15 @@ def keystone_H(src_w, src_h, dst_w, dst_h):
     return homo_from_pts(src, dst)
 
 
+def keystone_inset_H(src_w, src_h, dst_w, dst_h, inset=8.0):
+    """The keystone footprint pulled `inset` pixels inside the frame on every side: no tap of any frame of a jittered batch
+    touches the frame's edge (measurement aid: the all-interior case)."""
+    dst = np.array([[0, 0], [dst_w - 1, 0], [dst_w - 1, dst_h - 1], [0, dst_h - 1]], dtype=np.float64)
+    src = np.array([[0.2 * (src_w - 1), inset], [0.8 * (src_w - 1), inset], [src_w - 1 - inset, src_h - 1 - inset], [inset, src_h - 1 - inset]],
+                   dtype=np.float64)
+    return homo_from_pts(src, dst)
+
+
 def jitter_H(H, idx, px=2.0):
     """Per-frame variant: pre-multiply by a seeded +-px translation of the destination."""
     rng = np.random.default_rng(99 + idx)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Ablation builds of the warp kernel (measurement aid; the product source carries no ablation code).
+
+    python tools/ablate.py <name>=<spec>[+<spec>...] ...   ->  bev_amd/csrc/variants/<name>.so
+
+Each spec patches a COPY of warp_kernels.hip:
+    nostore   store_s keeps its operands alive and returns
+    noload    issue_s fabricates taps from the offsets (no vector memory loads)
+    noblend   finish_s xors the taps instead of blending
+    stsmall   stores go to a few KB per frame (no HBM write traffic)
+    ldsmall   taps come from the first 64 KB of the frame (cache hits)
+    gather    the launcher never picks the staged kernel
+Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bev_amd", "csrc")
+FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-undefined-internal".split()
+
+
+def patch(src, spec):
+    def rep(old, new):
+        nonlocal src
+        assert old in src, (spec, old[:60])
+        src = src.replace(old, new, 1)
+    if spec == "nostore":
+        rep("    auto store_s = [&](int y, const uint4 (&out)[NQ]) {\n",
+            "    auto store_s = [&](int y, const uint4 (&out)[NQ]) {\n"
+            "        asm volatile(\"\" ::\"v\"(out[0].x), \"v\"(out[0].y), \"v\"(out[0].z), \"v\"(out[0].w));\n        if (y != 12345678) return;\n")
+    elif spec == "noload":
+        rep("#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n",
+            "        for (int j = 0; j < PPL; j++)\n            for (int k = 0; k < WINB / 4; k++) t0[j].w[k] = S0[j] * (k + 3) + (uint32_t)(uintptr_t)b0, "
+            "t1[j].w[k] = S0[j] ^ (0x9e3779b9u * (k + 1));\n        if (cls != 12345678) return;\n"
+            "#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n")
+    elif spec == "noblend":
+        rep("            blend_put(j, w0, w1, fx, fy);\n        }\n    };\n",
+            "            wtr[64 * j + lane] = (w0[0] ^ w1[0] ^ w0[NEED - 1] ^ w1[NEED - 1]) + fx + fy;\n        }\n    };\n")
+    elif spec == "stsmall":
+        rep("            uint8_t* d = dframe + (int64_t)y * a.dst_rs + (int64_t)(x0 + lane * PPL) * C;\n",
+            "            uint8_t* d = dframe + (int64_t)(y & 7) * a.dst_rs + (int64_t)((x0 & 255) + lane * PPL) * C;\n")
+    elif spec == "ldsmall":
+        rep("            const uint32_t off = S0[j];\n", "            const uint32_t off = S0[j] & 0xffffu;\n")
+    elif spec == "notrans":  # 8-bit only: pixels stay in registers (lane-interleaved order goes to memory: wrong layout, same work minus LDS)
+        rep("    uint32_t* wtr = &s_tr[wave][0];\n", "    uint32_t* wtr = &s_tr[wave][0];\n    uint32_t tr_reg[4] = {0, 0, 0, 0};\n")
+        rep("            wtr[64 * j + lane] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);", "            tr_reg[j & 3] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);")
+        rep("    auto read_back = [&](uint4 (&out)[NQ]) {\n", "    auto read_back = [&](uint4 (&out)[NQ]) {\n        if (sizeof(T) == 1) { out[0] = make_uint4(tr_reg[0], tr_reg[1], tr_reg[2], tr_reg[3]); return; }\n")
+    elif spec == "notie":
+        rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
+    elif spec == "gather":
+        rep("        if (a.src_stage_ok) {\n            launch_mode<T, C, INTERP, kStaged>", "        if (a.src_stage_ok && a.batch < 0) {\n            launch_mode<T, C, INTERP, kStaged>")
+    else:
+        raise SystemExit("unknown spec " + spec)
+    return src
+
+
+def main():
+    base = open(os.path.join(CSRC, "warp_kernels.hip")).read()
+    os.makedirs(os.path.join(CSRC, "variants"), exist_ok=True)
+    procs = []
+    for arg in sys.argv[1:]:
+        name, specs = arg.split("=", 1)
+        src = base
+        for spec in [s for s in specs.split("+") if s]:
+            src = patch(src, spec)
+        tmp = "/tmp/ablate_%s.hip" % name
+        open(tmp, "w").write(src)
+        obj = "/tmp/ablate_%s.o" % name
+        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", tmp, "-o", obj]
+        procs.append((name, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE)))
+    for name, obj, p in procs:
+        err = p.communicate()[1].decode()
+        if p.returncode:
+            raise SystemExit("%s: %s" % (name, err[-2000:]))
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", os.path.join(CSRC, "variants", name + ".so"),
+                               os.path.join(CSRC, "bevwarp_api.o"), obj, os.path.join(CSRC, "geom_kernels.o")])
+        print("built", name)
+
+
+if __name__ == "__main__":
+    main()
