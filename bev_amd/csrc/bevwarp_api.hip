@@ -136,15 +136,15 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     a.dst_w = dst_w;
     a.m_stride = m_count == 1 ? 0 : 9;
     a.bw0 = block_width(dst_w, dst_h);
-    // tile = tile_width x tile_h destination pixels per workgroup.  16 rows (four per wave) is the floor; 8-bit pixels are
-    // ALU-bound enough for the per-wave set-up to show, so they take 32-row tiles when the launch still has >= 4096
-    // workgroups (16 per CU: footprints with large outside regions make workgroups uneven, and 64-row tiles lose more to
-    // the tail than they save)
+    // tile = tile_width x tile_h destination pixels per workgroup.  16 rows (four per wave) is the floor and what the
+    // HBM-bound float formats take; the ALU-bound 8-bit formats amortise the per-tile set-up over 24 rows once the launch
+    // fills the chip more than twice (taller tiles gain on footprints that lie inside the frame and lose on those the
+    // frame's edge cuts up, whose tiles differ widely in cost: A/B in DESIGN.md section 6).
     const int tw = tile_width(dtype);
     a.tile_h = rows_per_pass() * 4;
     if (dtype == BEVWARP_U8) {
         const int64_t per_row_of_tiles = (int64_t)batch * ((dst_w + tw - 1) / tw);
-        if (per_row_of_tiles * ((dst_h + 2 * a.tile_h - 1) / (2 * a.tile_h)) >= 4096) a.tile_h *= 2;
+        if (per_row_of_tiles * ((dst_h + 23) / 24) >= 2 * (int64_t)resident_workgroups(dtype, channels, interp)) a.tile_h = 24;
     }
 #ifdef BEVWARP_TILE_H  // experiments only
     a.tile_h = BEVWARP_TILE_H;
@@ -167,7 +167,6 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // bytes of float data
     const int dst_align = (dtype == BEVWARP_U8 && !po) ? (channels == 4 ? 16 : (channels == 2 ? 8 : 4)) : 16;
     a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0) && (dst_frame_stride % dst_align == 0);
-    a.src_stage_ok = ((uintptr_t)src % 16 == 0) && (src_row_stride % 16 == 0) && (src_frame_stride % 16 == 0);
     if (po) {
         a.planar = 1;
         a.dst_ps = po->plane_stride;

@@ -23,7 +23,6 @@ struct WarpArgs {
     int tile_h;                  // rows per workgroup (a multiple of the 4 rows one pass of its waves covers)
     int chunk;                   // items per XCD: grid = 8 * chunk
     int dst_vec_ok;              // destination layout admits the wide stores
-    int src_stage_ok;            // source rows start on 16-byte boundaries: tiles may be staged in LDS by 16-byte LDS-DMA
     float bval_f[4];
     uint8_t bval_u8[4];
     // planar float output of 8-bit warps (bevwarp_warp_planar): dst[c][y][x] = float(pixel) * pscale[c] + pbias[c]
@@ -34,6 +33,7 @@ struct WarpArgs {
 
 int tile_width(int dtype);   // destination pixels per row segment of one wave: 256 (8-bit) / 128 (float)
 int rows_per_pass();         // rows one pass of a workgroup's waves covers
+int resident_workgroups(int dtype, int channels, int interp);  // workgroups of this format's kernel the device holds at once
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);

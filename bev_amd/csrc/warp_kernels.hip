@@ -42,6 +42,18 @@ constexpr int kInterBits = 5;
 
 template <typename T>
 constexpr int pixels_per_lane() { return sizeof(T) == 1 ? 4 : 2; }
+// Ownership of the 64 x PPL pixels a wave computes per pass (a compile-time tag of the code that depends on it):
+//   RowSeg  one row segment of 64 PPL pixels: pixel j of lane l is (x0 + 64 j + l, y).  A pass reads two source rows of an
+//           axis-aligned map: the interior loop.
+//   BlkSeg  a block of 64 x PPL pixels: pixel j of lane l is (xb + l, y + j), xb = the wave's 64-pixel column strip of the
+//           tile.  Tiles that the frame's edge crosses are cut into these: the edge then runs through a quarter as many
+//           passes, and only those pay for guarded taps.
+struct RowSeg {
+    static constexpr bool blk = false;
+};
+struct BlkSeg {
+    static constexpr bool blk = true;
+};
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t d) {
     // magic = floor(2^32 / d) + 1, exact while n * d < 2^32 (host guarantees); magic == 0 -> plain division
@@ -298,42 +310,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef BEVWARP_U8LIN_WAVES
 #define BEVWARP_U8LIN_WAVES 3
 #endif
-#ifndef BEVWARP_STAGED_WAVES
-#define BEVWARP_STAGED_WAVES 4
-#endif
-// MODE: how an instantiation feeds its taps.  A tile is cut into groups of 4 rows (one per wave); a test of the group's four
-// corner pixels says whether the group can be STAGED (every pixel samples inside the frame, W of one sign, the source box
-// fits the LDS ring).
-//   kGather  every row through the software-pipelined gather loop (taps of the next row in flight in VGPRs: 3 waves per
-//            SIMD for 8-bit RGB bilinear).  Used when the source layout rules staging out.
-//   kStaged  the staged groups of a tile from LDS (no taps in flight in registers: 4 waves per SIMD, which is what the
-//            ALU-bound 8-bit bilinear formats need), then the tile's other rows -- the frame's edge crosses them, or their
-//            boxes do not fit -- through the same row classes one row at a time, within the same register budget.
-enum { kGather = 0, kStaged = 1 };
 // Diagnostic build only (-DBEVWARP_CLOCK, tools/clock.py): wave 0 of every workgroup adds the shader-clock ticks
 // (s_memtime) and the 100 MHz reference ticks (s_memrealtime) it lived for; their ratio is the clock the chip held.
 #ifdef BEVWARP_CLOCK
-__device__ unsigned long long g_clk[16];  // [0..2] life ticks / reference ticks / workgroups, [4..] ticks per phase of the row loop
-#define STAMP(i)                                                           \
-    do {                                                                   \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
-        phase_[i] += now_ - stamp_;                                        \
-        stamp_ = now_;                                                     \
-    } while (0)
-#else
-#define STAMP(i) do { } while (0)
+__device__ unsigned long long g_clk[4];
 #endif
-template <typename T, int C, int INTERP, int MODE>
-constexpr int waves_per_simd() {
-    return MODE == kStaged ? BEVWARP_STAGED_WAVES : ((sizeof(T) == 1 && C >= 3 && INTERP == kLinear) ? BEVWARP_U8LIN_WAVES : 4);
+// waves per SIMD a format's kernel is compiled for: what its interior loop needs without spilling
+constexpr int waves_per_simd_of(bool is_u8, int channels, int interp) {
+    return interp == kLinear && (is_u8 || channels == 4) ? BEVWARP_U8LIN_WAVES : 4;
 }
-// formats with a staged kernel (bilinear 8-bit pixels: the ones bound by vector-ALU issue)
 template <typename T, int C, int INTERP>
-constexpr bool has_staged_kernel() { return sizeof(T) == 1 && INTERP == kLinear; }
-template <typename T, int C, int INTERP, bool RS4, bool PLANAR, int MODE>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, C, INTERP, MODE>(), 8))) void warp_rows(const WarpArgs a) {
+constexpr int waves_per_simd() { return waves_per_simd_of(sizeof(T) == 1, C, INTERP); }
+template <typename T, int C, int INTERP, bool RS4, bool PLANAR>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, C, INTERP>(), 8))) void warp_rows(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
-    constexpr int TW = 64 * PPL;
+    constexpr int TW = 64 * PPL;                                 // tile width
+    constexpr int kStrips = PPL;                                 // 64-pixel column strips of a tile (block ownership)
+    constexpr int BR = PPL;                                      // rows of a block
     constexpr int PBs = (int)sizeof(T) * C;                      // source bytes per pixel
     constexpr int TAPB = INTERP == kLinear ? 2 * PBs : PBs;      // bytes of one row's taps
     constexpr int LOADB = (TAPB + 3) & ~3;                       // loaded per row (whole dwords)
@@ -350,20 +343,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     static_assert(!PLANAR || sizeof(T) == 1, "planar output is the 8-bit -> float32 egress path");
     static_assert(!RS4 || kAligned, "RS4 only qualifies the aligned-window variant");
     __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves][TRW];
-    // Staged tiles (8-bit pixels): the source box of every 4-row group of the tile goes to LDS by coalesced 16-byte
-    // LDS-DMA row loads, two groups in flight; taps are dword windows read from LDS (+ funnel shift when a pixel is not a
-    // whole number of dwords).  kPitch covers a TW-pixel segment magnified up to 1.9 x; a tile whose groups need more
-    // than kStageRows source rows or kPitch bytes per row takes the gather path below.
-    constexpr bool kStage = MODE == kStaged;
-    static_assert(!kStage || has_staged_kernel<T, C, INTERP>(), "no staged kernel for this format");
-    constexpr int kStageRows = 10;
-    constexpr int kPitch = ((TW * PBs * 19 / 10 + 48) + 255) & ~255;
-    constexpr int kBufBytes = kStageRows * kPitch;
-    constexpr bool kFunnel = (PBs % 4) != 0;
-    constexpr int NEED = LOADB / 4;                 // dwords of a tap row the blend takes, starting AT the left tap
-    constexpr int NDW = kFunnel ? NEED + 1 : NEED;  // dwords read per tap row (the aligned window around them)
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kStage ? 2 * kBufBytes : 16];
-
+    constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
 #ifdef BEVWARP_CLOCK
     struct ClockStamp {
         unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -416,6 +396,16 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     const double CX = uniform_f64((m0 * x0d + m2) * kTwo32), CY = uniform_f64((m3 * x0d + m5) * kTwo32), CW = uniform_f64(m6 * x0d + m8);
     const double RX = uniform_f64(m1 * kTwo32), RY = uniform_f64(m4 * kTwo32), RW = uniform_f64(m7);             // per destination row
     const double DX = uniform_f64(m0 * (64.0 * kTwo32)), DY = uniform_f64(m3 * (64.0 * kTwo32)), DW = uniform_f64(m6 * 64.0);  // per 64 pixels
+    // block ownership: xb = first pixel of the strip the coordinate stage works in, CXb.. = the row terms there (set_strip)
+    int xb = x0, strip_c = 0;
+    double CXb = CX, CYb = CY, CWb = CW;
+    auto set_strip = [&](int strip) __attribute__((always_inline)) {
+        if (strip == strip_c) return;
+        strip_c = strip;
+        xb = x0 + 64 * strip;
+        const double ds = (double)strip;
+        CXb = uniform_f64(__builtin_fma(ds, DX, CX)), CYb = uniform_f64(__builtin_fma(ds, DY, CY)), CWb = uniform_f64(__builtin_fma(ds, DW, CW));
+    };
     const double ld = (double)lane;
     const double cx0 = (m0 * kTwo32) * ld, cy0 = (m3 * kTwo32) * ld, cw0 = m6 * ld;                              // per lane
 
@@ -436,13 +426,15 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
     // the reference's chain for pixel j of this lane (rare: tie windows, SLOW rows); the matrix is re-read here so that the
     // row loop does not carry it in registers
-    auto exact_px = [&](int y, int j, int& Xe, int& Ye) __attribute__((always_inline)) {
+    auto exact_px = [&](auto own, int xs, int y, int j, int& Xe, int& Ye) __attribute__((always_inline)) {  // xs: the block's first pixel
+        constexpr bool kBlk = decltype(own)::blk;
         const double* Mp = M;
         asm volatile("" : "+s"(Mp));  // (keeps the loads below inside this rare branch)
         double Me[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Me[i] = Mp[i];
-        const int x = x0 + 64 * j + lane;
+        const int x = kBlk ? xs + lane : x0 + 64 * j + lane;
+        if (kBlk) y += j;
         const int bx = (int)(fast_div((uint32_t)x, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
         double X0, Y0, W0;
         row_terms(Me, bx, y, X0, Y0, W0);
@@ -453,16 +445,17 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     // Row state handed from the coordinate stage to the load / blend stages, 3 dwords per pixel:
     //   FAST      S0 = byte offset of the tap window, S1 / S2 = low dwords of tX / tY (fx, fy in bits 27..31)
     //   others    S0 = 0 (the dummy load), S1 / S2 = integer coordinates X, Y
-    int out_side = 0;  // set for an OUT row: which frame edge the segment lies beyond, and the sign of W
-    int end_sxa = 0, end_sya = 0, end_sxb = 0, end_syb = 0;  // source pixel of the two ends of the row coords_s saw last
     // the fast chain of one row segment: (high, low) dwords of tX / tY for the lane's pixels; returns the tie flag (0 = some
     // coordinate of this lane lies in a tie window) and the high dwords of the lane's first / last W
-    auto chain_u = [&](double UX, double UY, double UW, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL],
+    auto chain_u = [&](auto own, double UX, double UY, double UW, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL],
                        uint32_t& w_first, uint32_t& w_last) __attribute__((always_inline)) -> uint32_t {
+        constexpr bool kBlk = decltype(own)::blk;
+        // from pixel j to pixel j + 1 of a lane: 64 pixels along the row, or one row down
+        const double dX = kBlk ? RX : DX, dY = kBlk ? RY : DY, dW = kBlk ? RW : DW;
         double W[PPL], r[PPL];
         W[0] = UW + cw0;
 #pragma unroll
-        for (int j = 1; j < PPL; j++) W[j] = W[j - 1] + DW;
+        for (int j = 1; j < PPL; j++) W[j] = W[j - 1] + dW;
         // one reciprocal per lane: 1 / (W0 W1 [W2 W3]), then back-substitution
         if constexpr (PPL == 4) {
             const double p01 = W[0] * W[1], p23 = W[2] * W[3];
@@ -486,55 +479,69 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             hy[j] = (uint32_t)__double2hiint(ty_), ly[j] = (uint32_t)__double2loint(ty_);
             tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));
             if (j + 1 < PPL) {
-                Xn += DX;
-                Yn += DY;
+                Xn += dX;
+                Yn += dY;
             }
         }
         w_first = (uint32_t)__double2hiint(W[0]);
         w_last = (uint32_t)__double2hiint(W[PPL - 1]);
         return tie;
     };
-    auto chain = [&](int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL], uint32_t& w_first, uint32_t& w_last)
-                     __attribute__((always_inline)) -> uint32_t {
-        const double dy = (double)y;  // the row terms at the segment's first pixel
-        return chain_u(__builtin_fma(RX, dy, CX), __builtin_fma(RY, dy, CY), __builtin_fma(RW, dy, CW), hx, lx, hy, ly, w_first, w_last);
+    auto chain = [&](auto own, int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL], uint32_t& w_first,
+                     uint32_t& w_last) __attribute__((always_inline)) -> uint32_t {
+        constexpr bool kBlk = decltype(own)::blk;
+        const double dy = (double)y;  // the row terms at the first pixel of the segment / block
+        return chain_u(own, __builtin_fma(RX, dy, kBlk ? CXb : CX), __builtin_fma(RY, dy, kBlk ? CYb : CY), __builtin_fma(RW, dy, kBlk ? CWb : CW), hx,
+                       lx, hy, ly, w_first, w_last);
     };
     // rare: the lane's pixels that lie within 2^-19 of a rounding boundary (or are NaN) take the exact chain
-    auto fix_ties = [&](int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL]) __attribute__((always_inline)) {
+    auto fix_ties = [&](auto own, int xs, int y, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL])
+                        __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             if ((lx[j] & F::kTieMask) == 0 || (ly[j] & F::kTieMask) == 0) {
                 int Xe, Ye;
-                exact_px(y, j, Xe, Ye);
+                exact_px(own, xs, y, j, Xe, Ye);
                 int_to_fix<INTERP>(Xe, hx[j], lx[j]);
                 int_to_fix<INTERP>(Ye, hy[j], ly[j]);
             }
         }
     };
-    auto coords_s = [&](int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) -> int {
+    // (block ownership: y = the block's first row)
+    auto coords_s = [&](int strip, int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) -> int {
+        constexpr bool kBlk = true;
+        set_strip(strip);
         uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], w_first, w_last;
-        const uint32_t tie = chain(y, hx, lx, hy, ly, w_first, w_last);
+        const uint32_t tie = chain(BlkSeg{}, y, hx, lx, hy, ly, w_first, w_last);
         // -- classify the segment from its ends (pixel 0 of lane 0, pixel PPL-1 of lane 63), in scalar registers
         auto lane_u32 = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
         const uint32_t hxa = lane_u32(hx[0], 0), hya = lane_u32(hy[0], 0), hxb = lane_u32(hx[PPL - 1], 63), hyb = lane_u32(hy[PPL - 1], 63);
         const uint32_t wa = lane_u32(w_first, 0), wb = lane_u32(w_last, 63);
         const uint32_t ea = (wa >> 20) & 0x7ffu, eb = (wb >> 20) & 0x7ffu;  // 2^-199 .. 2^199: the shared reciprocal is safe
-        const bool w_ok = ((wa ^ wb) >> 31) == 0 && ea - 824u <= 398u && eb - 824u <= 398u;
+        bool w_ok = ((wa ^ wb) >> 31) == 0 && ea - 824u <= 398u && eb - 824u <= 398u;
+        // a block has two more corners (W is linear: one sign at the four corners = one sign inside)
+        const uint32_t hxc = kBlk ? lane_u32(hx[0], 63) : hxa, hyc = kBlk ? lane_u32(hy[0], 63) : hya;
+        const uint32_t hxd = kBlk ? lane_u32(hx[PPL - 1], 0) : hxb, hyd = kBlk ? lane_u32(hy[PPL - 1], 0) : hyb;
+        if (kBlk) w_ok = w_ok && ((wa ^ lane_u32(w_first, 63)) >> 31) == 0 && ((wa ^ lane_u32(w_last, 0)) >> 31) == 0;
         // source pixel of the two ends (a high dword outside the binade gives |s| >= 2^19: outside every limit below)
         const int sxa = (int)(hxa - kHiBias), sya = (int)(hya - kHiBias), sxb = (int)(hxb - kHiBias), syb = (int)(hyb - kHiBias);
-        end_sxa = sxa, end_sya = sya, end_sxb = sxb, end_syb = syb;
+        const int sxc = (int)(hxc - kHiBias), syc = (int)(hyc - kHiBias), sxd = (int)(hxd - kHiBias), syd = (int)(hyd - kHiBias);
         const bool in = can_fast && w_ok && (uint32_t)(sxa - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(sxb - kM) <= (uint32_t)(sxw_lim - 2 * kM) &&
-                        (uint32_t)(sya - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syb - kM) <= (uint32_t)(sy_lim - 2 * kM);
+                        (uint32_t)(sya - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syb - kM) <= (uint32_t)(sy_lim - 2 * kM) &&
+                        (uint32_t)(sxc - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(sxd - kM) <= (uint32_t)(sxw_lim - 2 * kM) &&
+                        (uint32_t)(syc - kM) <= (uint32_t)(sy_lim - 2 * kM) && (uint32_t)(syd - kM) <= (uint32_t)(sy_lim - 2 * kM);
         int cls = kFast;
         if (__builtin_expect(!in, 0)) {  // (the common class costs no further scalar work)
-            const bool e_ok = (((hxa ^ kHiExp) | (hya ^ kHiExp) | (hxb ^ kHiExp) | (hyb ^ kHiExp)) >> 20) == 0;  // all four inside the binade
-            const bool out = (sxa <= -3 && sxb <= -3) || (sxa > a.src_w && sxb > a.src_w) || (sya <= -3 && syb <= -3) || (sya > a.src_h && syb > a.src_h);
+            const bool e_ok = (((hxa ^ kHiExp) | (hya ^ kHiExp) | (hxb ^ kHiExp) | (hyb ^ kHiExp) | (hxc ^ kHiExp) | (hyc ^ kHiExp) | (hxd ^ kHiExp) |
+                                (hyd ^ kHiExp)) >> 20) == 0;  // every corner inside the binade
+            const int sx_hi = max(max(sxa, sxb), max(sxc, sxd)), sx_lo = min(min(sxa, sxb), min(sxc, sxd));
+            const int sy_hi = max(max(sya, syb), max(syc, syd)), sy_lo = min(min(sya, syb), min(syc, syd));
+            const bool out = sx_hi <= -3 || sx_lo > a.src_w || sy_hi <= -3 || sy_lo > a.src_h;
             // kEdge: W of one sign and both ends representable => every pixel between them is (the map is monotone along
             // the segment), taps need guards
             cls = !(e_ok && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
-            out_side = ((sxa <= -3 && sxb <= -3) ? 1 : (sxa > a.src_w && sxb > a.src_w) ? 2 : (sya <= -3 && syb <= -3) ? 3 : 4) | (int)((wa >> 31) << 3);
         }
-        if (tie == 0 && cls != kSlow) fix_ties(y, hx, lx, hy, ly);
+        if (tie == 0 && cls != kSlow) fix_ties(BlkSeg{}, xb, y, hx, lx, hy, ly);
         if (__builtin_expect(cls == kFast, 1)) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -656,11 +663,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         for (int j = 0; j < PPL; j++) put_px(j, v);
     };
     // SLOW row: exact chain and guarded taps for each of the lane's pixels (same ownership, same store order)
-    auto slow_s = [&](int y) __attribute__((always_inline)) {
+    auto slow_s = [&](int xs, int y) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             int Xe, Ye;
-            exact_px(y, j, Xe, Ye);
+            exact_px(BlkSeg{}, xs, y, j, Xe, Ye);
             put_px(j, sample_global<T, C, INTERP>(view, Xe, Ye));
         }
     };
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
         asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
     };
-    auto finish_any = [&](int cls, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
+    auto finish_any = [&](int cls, int xs, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
                           const Bytes<WINB> (&t1)[PPL]) {
         if (__builtin_expect(cls == kFast, 1)) {
             finish_s(S0, S1, S2, t0, t1);
@@ -740,21 +747,25 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             else if (cls == kEdge)
                 edge_s(S1, S2);
             else
-                slow_s(y);
+                slow_s(xs, y);
         }
     };
 
     // -- stores.  The destination is written once and never read back by this kernel: non-temporal stores keep it from
     // displacing source lines in L2 / MALL.  Lanes of a ragged last tile (and every lane when the destination's layout
     // does not admit the wide stores) fall back to element stores.
-    const int seg_px = min(TW, a.dst_w - x0);                         // valid pixels of this tile's row segments (> 0)
-    const int lane_px = max(0, min(PPL, seg_px - lane * PPL));        // 8-bit: valid pixels of this lane's store unit
-    const bool lane_vec = a.dst_vec_ok && lane_px == PPL;
-    auto store_s = [&](int y, const uint4 (&out)[NQ]) {
+    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {  // xs = first pixel of the segment / block
+        constexpr bool kBlk = decltype(own)::blk;
+        const int seg_px = min(kBlk ? 64 : TW, a.dst_w - xs);  // valid pixels of a row of the segment / block
+        // 8-bit: a lane stores 4 consecutive pixels: of the wave's row (pixels 4 l ..), or of row l / 16 of its block (pixels 4 (l % 16) ..)
+        const int st_row = kBlk ? lane >> 4 : 0, st_x = kBlk ? xs + (lane & 15) * PPL : xs + lane * PPL;
+        const int lane_px = max(0, min(PPL, a.dst_w - st_x));  // valid pixels of this lane's store unit
+        const bool lane_vec = a.dst_vec_ok && lane_px == PPL;
         if constexpr (sizeof(T) == 1) {  // the lane's 4 pixels = 4 C contiguous bytes, one instruction
             const uint32_t p[4] = {out[0].x, out[0].y, out[0].z, out[0].w};
             if constexpr (PLANAR) {  // float planes: one 16-byte store per channel
-                uint8_t* dp = dframe + (int64_t)y * a.dst_rs + (int64_t)(x0 + lane * PPL) * 4;
+                if (kBlk && y + st_row > y_last) return;
+                uint8_t* dp = dframe + (int64_t)(y + st_row) * a.dst_rs + (int64_t)st_x * 4;
 #pragma unroll
                 for (int k = 0; k < C; k++) {
                     const float sc = a.pscale[k], bi = a.pbias[k];
@@ -769,7 +780,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                 }
                 return;
             }
-            uint8_t* d = dframe + (int64_t)y * a.dst_rs + (int64_t)(x0 + lane * PPL) * C;
+            if (kBlk && y + st_row > y_last) return;
+            uint8_t* d = dframe + (int64_t)(y + st_row) * a.dst_rs + (int64_t)st_x * C;
             if (__builtin_expect(lane_vec, 1)) {
                 if constexpr (C == 1) {
                     __builtin_nontemporal_store(p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24), reinterpret_cast<uint32_t*>(d));
@@ -789,187 +801,36 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                     for (int k = 0; k < C; k++) d[i * C + k] = (uint8_t)(p[i] >> (8 * k));
             }
         } else {
-            float* drow = reinterpret_cast<float*>(dframe + (int64_t)y * a.dst_rs) + (int64_t)x0 * C;  // the wave's row segment
-            const int nfl = seg_px * C;  // valid floats of the segment
+            const int nfl = seg_px * C;  // valid floats of a row of the segment / block
+            constexpr int kRowUnits = 64 * C / 4;  // 16-byte units per 64-pixel row (block ownership)
 #pragma unroll
             for (int u = 0; u < NQ; u++) {
                 const int q = u * 64 + lane;
                 if (q >= kVec) continue;
-                if (__builtin_expect(a.dst_vec_ok && 4 * q + 4 <= nfl, 1)) {
+                const int r = kBlk ? q / kRowUnits : 0, qr = kBlk ? q - r * kRowUnits : q;  // row of the block, unit within the row
+                if (kBlk && y + r > y_last) continue;
+                float* drow = reinterpret_cast<float*>(dframe + (int64_t)(y + r) * a.dst_rs) + (int64_t)xs * C;
+                if (__builtin_expect(a.dst_vec_ok && 4 * qr + 4 <= nfl, 1)) {
                     u32x4 o = {out[u].x, out[u].y, out[u].z, out[u].w};
-                    __builtin_nontemporal_store(o, &reinterpret_cast<u32x4*>(drow)[q]);
+                    __builtin_nontemporal_store(o, &reinterpret_cast<u32x4*>(drow)[qr]);
                 } else {
                     const uint32_t f[4] = {out[u].x, out[u].y, out[u].z, out[u].w};
-                    for (int i = 0; i < 4 && 4 * q + i < nfl; i++) reinterpret_cast<uint32_t*>(drow)[4 * q + i] = f[i];
+                    for (int i = 0; i < 4 && 4 * qr + i < nfl; i++) reinterpret_cast<uint32_t*>(drow)[4 * qr + i] = f[i];
                 }
             }
         }
     };
 
-    // ===== staged tiles ================================================================================
-    // A tile is processed in groups of 4 rows (one per wave).  A group all of whose pixels sample inside the frame (its
-    // corner pixels do, W of one sign: the image of the group is the convex quadrilateral of its corners) and whose
-    // source box fits the LDS ring is STAGED: box(g + 1) streams into LDS while the waves blend group g from LDS.  The
-    // other groups of the tile take the row classes directly.  One barrier per group.
-    uint32_t ok_groups = 0;  // bit g: group g of this tile is staged
-    if constexpr (kStage) {
-        const int ng = (y_last - y0) / kWaves + 1;  // groups of this tile (tile_h / 4 <= 16: one lane per group corner)
-        if (a.src_stage_ok && can_fast && ng <= 16) {
-            // -- corner k of group g in lane 4 g + k: the fast chain for one pixel
-            const int cg = lane >> 2, ck = lane & 3;
-            const bool lane_on = cg < ng;
-            const int cyy = min(y0 + cg * kWaves + ((ck & 2) ? kWaves - 1 : 0), y_last);
-            const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)cyy;
-            const double cW = __builtin_fma(RW, cdy, CW) + m6 * cdx;
-            const double cr = rcp_newton(cW);
-            const double ctx = __builtin_fma(__builtin_fma(RX, cdy, CX) + (m0 * kTwo32) * cdx, cr, F::kMagic);
-            const double cty = __builtin_fma(__builtin_fma(RY, cdy, CY) + (m3 * kTwo32) * cdx, cr, F::kMagic);
-            const int csx = (int)((uint32_t)__double2hiint(ctx) - kHiBias), csy = (int)((uint32_t)__double2hiint(cty) - kHiBias);
-            const uint32_t cwh = (uint32_t)__double2hiint(cW);
-            const bool c_in = (uint32_t)(csx - kM) <= (uint32_t)(sxw_lim - 2 * kM) && (uint32_t)(csy - kM) <= (uint32_t)(sy_lim - 2 * kM) &&
-                              ((cwh >> 20) & 0x7ffu) - 824u <= 398u;
-            // min / max over the 4 corners of a group (a quad of lanes): two DPP quad permutes each
-            auto quad_min = [](int v) {
-                v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-                return min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-            };
-            const int gx0 = quad_min(csx) - 1, gx1 = -quad_min(-csx) + 1, gy0 = quad_min(csy) - 1, gy1 = -quad_min(-csy) + 1;  // +-1 px: the exact
-            // chain may move a coordinate by one unit; taps reach one pixel further right / down
-            constexpr int kTapPx = INTERP == kLinear ? 1 : 0;
-            const int g_rows = gy1 + kTapPx + 1 - gy0;                    // source rows gy0 .. gy1 + kTapPx
-            const int g_b0 = (gx0 * PBs) & ~15;                           // first staged byte of a row (16-byte aligned: rows are)
-            const int g_end = (gx1 + kTapPx + 1) * PBs;                   // one byte past the last tap
-            const int g_chunks = (g_end - g_b0 + 15) >> 4;                // 16-byte chunks per row
-            // the last chunk may read up to 15 bytes past its row: it must stay inside the frame's allocation
-            const bool g_tail_ok = (int64_t)(gy1 + kTapPx) * a.src_rs + g_b0 + 16 * (int64_t)g_chunks <= (int64_t)(a.src_h - 1) * a.src_rs + (int64_t)a.src_w * PBs;
-            const bool g_fit = gx0 >= 0 && gy0 >= 0 && g_rows <= kStageRows && g_chunks * 16 <= kPitch && g_tail_ok;
-            // a group can be staged when its four corners sample inside, its box fits, and W has one sign over it; bit g of
-            // ok_groups says so (the four lanes of a quad vote)
-            const uint64_t in_mask = __ballot(lane_on && c_in && g_fit), neg_mask = __ballot(lane_on && (cwh >> 31));
-            for (int g = 0; g < ng; g++) {
-                const uint32_t q_in = (uint32_t)(in_mask >> (4 * g)) & 0xFu, q_neg = (uint32_t)(neg_mask >> (4 * g)) & 0xFu;
-                if (q_in == 0xFu && (q_neg == 0u || q_neg == 0xFu)) ok_groups |= 1u << g;
-            }
-            if (ok_groups != 0) {
-                auto group_i = [](int v, int g) { return __builtin_amdgcn_readlane(v, 4 * g); };
-                auto staged_group = [&](int g) { return g < ng && ((ok_groups >> g) & 1u) != 0; };
-                // -- stage(g): rows of the box are dealt to the waves; lane i moves chunk i (+ 64, ...) of its row
-                auto stage = [&](int g) __attribute__((always_inline)) {
-                    const int r0 = group_i(gy0, g), nr = group_i(g_rows, g), b0 = group_i(g_b0, g), nch = group_i(g_chunks, g);
-                    uint8_t* buf = s_stage + (g & 1) * kBufBytes;
-                    for (int rr = wave; rr < nr; rr += kWaves) {
-                        const uint8_t* grow = frame + (int64_t)(r0 + rr) * a.src_rs + b0 + lane * 16;
-                        uint8_t* lrow = buf + rr * kPitch;
-#pragma unroll
-                        for (int c0 = 0; c0 < kPitch / 16; c0 += 64) {
-                            if (c0 < nch && lane + c0 < nch)
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + c0 * 16),
-                                                                 (__attribute__((address_space(3))) void*)(lrow + c0 * 16), 16, 0, 0);
-                        }
-                    }
-                };
-                uint4 out[NQ];
-                int y_prev = -1;
-                if (staged_group(0)) stage(0);
-                for (int g = 0; g < ng; g++) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of box g has landed (and row g - 2 is stored)
-                    __builtin_amdgcn_s_barrier();                      // ... and everybody else's; every wave is done reading box g - 1
-                    if (staged_group(g + 1)) stage(g + 1);
-                    if (y_prev >= 0) read_back(out);  // row g - 1 out of the transposition row (written a whole group ago: no LDS latency)
-                    const int y = y0 + g * kWaves + wave;
-                    const bool on = y <= y_last && staged_group(g);  // (the other groups follow below)
-                    uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
-                    uint32_t raw0[PPL][NDW], raw1[PPL][NDW], o[PPL];
-                    if (on) {
-                        if (chain(y, hx, lx, hy, ly, wf_, wl_) == 0) fix_ties(y, hx, lx, hy, ly);
-                        // LDS byte offset of a pixel's left tap, from the high dwords: (sy - r0) * kPitch + sx * PBs - b0
-                        const uint32_t kL = (uint32_t)(-(group_i(gy0, g) * kPitch) - group_i(g_b0, g)) - 0x380000u * (uint32_t)(kPitch + PBs);
-                        const uint8_t* buf = s_stage + (g & 1) * kBufBytes;
-#pragma unroll
-                        for (int j = 0; j < PPL; j++) {
-                            o[j] = __umul24(hy[j], (uint32_t)kPitch) + (__umul24(hx[j], (uint32_t)PBs) + kL);
-                            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(buf + (kFunnel ? (o[j] & ~3u) : o[j]));
-#pragma unroll
-                            for (int k = 0; k < NDW; k++) {
-                                raw0[j][k] = p0[k];
-                                if (INTERP == kLinear) raw1[j][k] = p0[k + kPitch / 4];
-                            }
-                        }
-                    }
-                    if (y_prev >= 0) store_s(y_prev, out);  // behind the DMA and the tap reads: a whole group of arithmetic to complete
-                    y_prev = -1;
-                    if (on) {
-#pragma unroll
-                        for (int j = 0; j < PPL; j++) {
-                            uint32_t w0[NEED], w1[NEED];
-#pragma unroll
-                            for (int k = 0; k < NEED; k++) {
-                                if constexpr (kFunnel) {
-                                    w0[k] = __builtin_amdgcn_alignbit(raw0[j][k + 1], raw0[j][k], o[j] << 3);
-                                    w1[k] = INTERP == kLinear ? __builtin_amdgcn_alignbit(raw1[j][k + 1], raw1[j][k], o[j] << 3) : 0u;
-                                } else {
-                                    w0[k] = raw0[j][k];
-                                    w1[k] = INTERP == kLinear ? raw1[j][k] : 0u;
-                                }
-                            }
-                            blend_put(j, w0, w1, lx[j] >> 27, ly[j] >> 27);
-                        }
-                        y_prev = y;
-                    }
-                }
-                if (y_prev >= 0) read_back(out);
-                if (y_prev >= 0) store_s(y_prev, out);
-            }
-        }
-    }
-
-    // -- kStaged: the rows of the groups that were not staged, one at a time (load -> wait -> blend -> store).  The waves
-    // of the other workgroups on the CU cover the exposed latency; what matters is that this path fits the staged loop's
-    // register budget.
-    if constexpr (kStage) {
-#ifdef BEVWARP_EXP_NODIRECT
-        return;
-#endif
-        uint32_t A0[PPL], A1[PPL], A2[PPL];
-        Bytes<WINB> u0[PPL], u1[PPL];
-        uint4 out[NQ];
-        int y = y0 + wave;
-        if (y > y_last) return;
-        if (ok_groups == 0) {  // (the probe of the gather loop below: a wave whose rows all lie beyond one frame edge)
-            if (coords_s(y, A0, A1, A2) == kOut && y + kWaves <= y_last) {
-                const int side0 = out_side;
-                const int y_probe = y + ((y_last - y) / kWaves) * kWaves;
-                if (coords_s(y_probe, A0, A1, A2) == kOut && out_side == side0) {
-                    fill_s();
-                    read_back(out);
-                    for (; y <= y_last; y += kWaves) store_s(y, out);
-                    return;
-                }
-            }
-        }
-        for (int g = 0; y <= y_last; g++, y += kWaves) {
-            if ((ok_groups >> g) & 1u) continue;
-            const int cls = coords_s(y, A0, A1, A2);
-            issue_s(cls, A0, u0, u1);
-            finish_any(cls, y, A0, A1, A2, u0, u1);
-            read_back(out);
-            store_s(y, out);
-        }
-        return;
-    }
     // -- the row loop.  Rows of a tile are dealt to its waves round-robin: neighbouring rows share source lines and run
     // at the same time.
-    constexpr int RSTEP = kWaves;
-    int yf = y0 + wave;
-    const int y_end = y_last;
-    if (yf > y_end) return;
     uint32_t A0[PPL], A1[PPL], A2[PPL], B0[PPL], B1[PPL], B2[PPL];  // row state: current / next
     Bytes<WINB> u0[PPL], u1[PPL];
     uint4 out[NQ];
     // -- interior tiles.  When the tile's four corner pixels sample inside the frame by the FAST margin with W of one sign,
     // the tile maps into the convex quadrilateral of their images: every row is FAST and the loop needs no row classes --
     // no end-pixel read-out, no scalar decisions, row terms advanced by one addition each.
-    bool tile_in;
+    // -- the tile's four corner pixels decide how it is processed
+    bool tile_in, tile_slanted, tile_out;
     {
         const int ck = lane & 3;
         const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)((ck & 2) ? y_last : y0);
@@ -977,137 +838,162 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         const double cr = rcp_newton(cW);
         const double ctx = __builtin_fma(__builtin_fma(RX, cdy, CX) + (m0 * kTwo32) * cdx, cr, F::kMagic);
         const double cty = __builtin_fma(__builtin_fma(RY, cdy, CY) + (m3 * kTwo32) * cdx, cr, F::kMagic);
-        const int csx = (int)((uint32_t)__double2hiint(ctx) - kHiBias), csy = (int)((uint32_t)__double2hiint(cty) - kHiBias);
+        const uint32_t chx = (uint32_t)__double2hiint(ctx), chy = (uint32_t)__double2hiint(cty);
+        const int csx = (int)(chx - kHiBias), csy = (int)(chy - kHiBias);
         const uint32_t cwh = (uint32_t)__double2hiint(cW);
+        const bool c_w = ((cwh >> 20) & 0x7ffu) - 824u <= 398u;
         // (one pixel more than the rows' own margin: the exact chain may move a coordinate by a unit)
-        const bool c_in = (uint32_t)(csx - kM - 1) <= (uint32_t)(sxw_lim - 2 * kM - 2) && (uint32_t)(csy - kM - 1) <= (uint32_t)(sy_lim - 2 * kM - 2) &&
-                          ((cwh >> 20) & 0x7ffu) - 824u <= 398u;
+        const bool c_in = (uint32_t)(csx - kM - 1) <= (uint32_t)(sxw_lim - 2 * kM - 2) && (uint32_t)(csy - kM - 1) <= (uint32_t)(sy_lim - 2 * kM - 2) && c_w;
         const uint32_t in4 = (uint32_t)__ballot(c_in) & 0xFu, neg4 = (uint32_t)__ballot((cwh >> 31) != 0) & 0xFu;
-        tile_in = can_fast && sxw_lim >= 2 * kM + 2 && sy_lim >= 2 * kM + 2 && in4 == 0xFu && (neg4 == 0u || neg4 == 0xFu);
+        const bool one_sign = neg4 == 0u || neg4 == 0xFu;
+        // interior: every pixel of the tile samples inside the frame (the tile maps into the convex quadrilateral of its
+        // corners' images) -- no row classes at all
+        tile_in = can_fast && sxw_lim >= 2 * kM + 2 && sy_lim >= 2 * kM + 2 && in4 == 0xFu && one_sign;
+        // outside: all four corners beyond the same frame edge (coordinates representable, W sane) -- the border value
+        const bool c_rep = c_w && (((chx ^ kHiExp) | (chy ^ kHiExp)) >> 20) == 0;
+        auto all4 = [](bool v) { return ((uint32_t)__ballot(v) & 0xFu) == 0xFu; };
+        tile_out = fill_ok && one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > a.src_w) || all4(csy <= -3) || all4(csy > a.src_h));
+        // source rows a row of the tile runs through, per 64 pixels.  Past ~14 (a 256-pixel segment crossing ~56 rows, e.g.
+        // a 1.4 x minifying map turned by 10 degrees) every lane of a gather instruction sits in a line of its own and the
+        // row segments lose to compact blocks (A/B over rotation angles: DESIGN.md section 6)
+        const int run_top = abs(__builtin_amdgcn_readlane(csy, 1) - __builtin_amdgcn_readlane(csy, 0));
+        const int run_bot = abs(__builtin_amdgcn_readlane(csy, 3) - __builtin_amdgcn_readlane(csy, 2));
+        tile_slanted = max(run_top, run_bot) > 14 * kStrips;
     }
-    if (tile_in) {
-        double UX = __builtin_fma(RX, (double)yf, CX), UY = __builtin_fma(RY, (double)yf, CY), UW = __builtin_fma(RW, (double)yf, CW);
-        const double SX = uniform_f64(RX * (double)RSTEP), SY = uniform_f64(RY * (double)RSTEP), SW = uniform_f64(RW * (double)RSTEP);
-        // coordinates of the NEXT row of this wave (each call advances the row terms)
-        int y_next = yf;
-        auto coords_f = [&](uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
+    // -- the passes of this wave over the tile, in order.
+    //   row segments: rows y0 + w + 4 i (neighbouring rows share source lines and run at the same time)
+    //   blocks:       strip after strip; inside a strip the four waves take neighbouring blocks (rotated by the strip index so
+    //                 that a ragged tile height does not always short-change the same wave): together they walk a compact
+    //                 64 x 4 BR patch of the destination at any time, which is what keeps a rotated footprint in L1
+    struct Pass {
+        int strip, y;
+    };
+    const int n_strips = (min(TW, a.dst_w - x0) + 63) >> 6;
+    auto first_pass = [&](auto own, Pass& p) __attribute__((always_inline)) -> bool {
+        constexpr bool kBlk = decltype(own)::blk;
+        p.strip = 0;
+        p.y = kBlk ? y0 + BR * wave : y0 + wave;
+        if (!kBlk) return p.y <= y_last;
+        while (p.y > y_last) {
+            if (++p.strip >= n_strips) return false;
+            p.y = y0 + BR * ((wave + p.strip) & (kWaves - 1));
+        }
+        return true;
+    };
+    auto next_pass = [&](auto own, Pass& p) __attribute__((always_inline)) -> bool {
+        constexpr bool kBlk = decltype(own)::blk;
+        p.y += kBlk ? BR * kWaves : kWaves;
+        if (!kBlk) return p.y <= y_last;
+        while (p.y > y_last) {
+            if (++p.strip >= n_strips) return false;
+            p.y = y0 + BR * ((wave + p.strip) & (kWaves - 1));
+        }
+        return true;
+    };
+    auto pass_x = [&](const Pass& p) { return x0 + 64 * p.strip; };
+
+    if (tile_out) {  // every pixel of the tile is the border value
+        Pass p;
+        if (!first_pass(BlkSeg{}, p)) return;
+        fill_s();
+        read_back(out);
+        do store_s(BlkSeg{}, pass_x(p), p.y, out);
+        while (next_pass(BlkSeg{}, p));
+        return;
+    }
+    // -- interior tiles: no row classes; software-pipelined (the next pass's loads in flight, the pass after that getting its
+    // coordinates, while the previous one is stored and the current one blended)
+    auto interior = [&](auto own) __attribute__((always_inline)) {
+        constexpr bool kBlk = decltype(own)::blk;
+        Pass p_cur, p_nxt;  // p_cur: the pass whose pixels sit in the LDS row; p_nxt: the pass whose coordinates are in the C state
+        if (!first_pass(own, p_nxt)) return;
+        // row terms of the pass the coordinate stage is at; a row segment's advance by one addition per pass
+        double UX = 0, UY = 0, UW = 0;
+        const double SX = uniform_f64(RX * (double)kWaves), SY = uniform_f64(RY * (double)kWaves), SW = uniform_f64(RW * (double)kWaves);
+        if (!kBlk) UX = __builtin_fma(RX, (double)p_nxt.y, CX), UY = __builtin_fma(RY, (double)p_nxt.y, CY), UW = __builtin_fma(RW, (double)p_nxt.y, CW);
+        auto coords_f = [&](const Pass& p, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
             uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
-            if (chain_u(UX, UY, UW, hx, lx, hy, ly, wf_, wl_) == 0) fix_ties(y_next, hx, lx, hy, ly);
+            uint32_t tie;
+            if constexpr (kBlk) {
+                set_strip(p.strip);
+                tie = chain(own, p.y, hx, lx, hy, ly, wf_, wl_);
+            } else {
+                tie = chain_u(own, UX, UY, UW, hx, lx, hy, ly, wf_, wl_);
+                UX += SX;
+                UY += SY;
+                UW += SW;
+            }
+            if (tie == 0) fix_ties(own, xb, p.y, hx, lx, hy, ly);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 S0[j] = __umul24(hy[j], rs32) + (__umul24(hx[j], (uint32_t)PBs) + kOff);
                 S1[j] = lx[j];
                 S2[j] = ly[j];
             }
-            UX += SX;
-            UY += SY;
-            UW += SW;
-            y_next += RSTEP;
         };
-        // one step: row yf's pixels leave the LDS row, the next row's loads are issued from state C, the row after that
-        // gets its coordinates into state N, row yf is stored, the next row is blended
-        bool more = yf + RSTEP <= y_end;
+        bool more;
         auto step = [&](uint32_t (&C0)[PPL], uint32_t (&C1)[PPL], uint32_t (&C2)[PPL], uint32_t (&N0)[PPL], uint32_t (&N1)[PPL], uint32_t (&N2)[PPL])
                         __attribute__((always_inline)) {
-            read_back(out);
+            read_back(out);  // p_cur's pixels (written a step ago: no LDS latency on the path)
             issue_s(kFast, C0, u0, u1);
-            const int y_done = yf;
-            yf += RSTEP;
-            more = yf + RSTEP <= y_end;
-            if (more) coords_f(N0, N1, N2);
-            store_s(y_done, out);
+            const Pass p_st = p_cur;
+            p_cur = p_nxt;
+            more = next_pass(own, p_nxt);
+            if (more) coords_f(p_nxt, N0, N1, N2);
+            store_s(own, pass_x(p_st), p_st.y, out);  // behind the loads: vmcnt retires in issue order
             finish_s(C0, C1, C2, u0, u1);
         };
-        coords_f(A0, A1, A2);
+        coords_f(p_nxt, A0, A1, A2);
         issue_s(kFast, A0, u0, u1);
-        if (more) coords_f(B0, B1, B2);
+        p_cur = p_nxt;
+        more = next_pass(own, p_nxt);
+        if (more) coords_f(p_nxt, B0, B1, B2);
         finish_s(A0, A1, A2, u0, u1);
-        while (more) {  // (two steps per trip: the row states swap roles instead of being copied)
+        while (more) {  // (two steps per trip: the states swap roles instead of being copied)
             step(B0, B1, B2, A0, A1, A2);
             if (!more) break;
             step(A0, A1, A2, B0, B1, B2);
         }
         read_back(out);
-        store_s(yf, out);
+        store_s(own, pass_x(p_cur), p_cur.y, out);
+    };
+    if (tile_in) {
+        if (tile_slanted)
+            interior(BlkSeg{});
+        else
+            interior(RowSeg{});
         return;
     }
-#ifdef BEVWARP_DIRECT_EDGE
+    // -- the frame's edge crosses the tile (or W changes sign in it): blocks with a class each, the same pipeline
     {
-        int cls = coords_s(yf, A0, A1, A2);
-        if (cls == kOut && yf + RSTEP <= y_end) {
-            const int side0 = out_side;
-            const int y_probe = yf + ((y_end - yf) / RSTEP) * RSTEP;
-            if (coords_s(y_probe, B0, B1, B2) == kOut && out_side == side0) {
-                fill_s();
-                read_back(out);
-                for (int y = yf; y <= y_end; y += RSTEP) store_s(y, out);
-                return;
-            }
-        }
-        for (;;) {
-            issue_s(cls, A0, u0, u1);
-            finish_any(cls, yf, A0, A1, A2, u0, u1);
-            read_back(out);
-            store_s(yf, out);
-            yf += RSTEP;
-            if (yf > y_end) return;
-            cls = coords_s(yf, A0, A1, A2);
-        }
-    }
-#endif
-    int cls_c = coords_s(yf, A0, A1, A2), cls_n = kSlow;
-    if (cls_c == kOut && yf + RSTEP <= y_end) {
-        // The wave's first row lies beyond a frame edge: probe its last row.  When that one lies beyond the same edge
-        // with W of the same sign, the rows between them map into the convex hull of the two segments and see nothing
-        // of the frame either: fill them without computing another coordinate.  (Footprints like the Brno BEV have a
-        // third of their rows outside; a wave whose first row is inside never pays for this.)
-        const int side0 = out_side;
-        const int y_probe = yf + ((y_end - yf) / RSTEP) * RSTEP;
-        if (coords_s(y_probe, B0, B1, B2) == kOut && out_side == side0) {
-            fill_s();
-            read_back(out);
-            for (int y = yf; y <= y_end; y += RSTEP) store_s(y, out);
-            return;
-        }
-    }
-    issue_s(cls_c, A0, u0, u1);
-    // Order inside an iteration: the previous row's pixels out of the LDS row (written an iteration ago: no LDS latency
-    // on the path), the next row's loads, the next-but-one row's coordinates, THEN the previous row's store, then the
-    // blend.  vmcnt retires in issue order, so a store issued before a row's loads would have to reach L2 before that
-    // row's taps can be used; issued after them it has a whole iteration to complete.
-    bool more = yf + RSTEP <= y_end;
-    if (more) cls_n = coords_s(yf + RSTEP, B0, B1, B2);
-    finish_any(cls_c, yf, A0, A1, A2, u0, u1);
-#ifdef BEVWARP_CLOCK
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime(), phase_[4] = {0, 0, 0, 0};
-#endif
-    while (more) {
+        Pass p_cur, p_nxt;
+        if (!first_pass(BlkSeg{}, p_nxt)) return;
+        int cls_c = coords_s(p_nxt.strip, p_nxt.y, A0, A1, A2), cls_n = kSlow;
+        issue_s(cls_c, A0, u0, u1);
+        p_cur = p_nxt;
+        bool more = next_pass(BlkSeg{}, p_nxt);
+        if (more) cls_n = coords_s(p_nxt.strip, p_nxt.y, B0, B1, B2);
+        finish_any(cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
+        while (more) {
 #pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            A0[j] = B0[j];
-            A1[j] = B1[j];
-            A2[j] = B2[j];
+            for (int j = 0; j < PPL; j++) {
+                A0[j] = B0[j];
+                A1[j] = B1[j];
+                A2[j] = B2[j];
+            }
+            cls_c = cls_n;
+            read_back(out);
+            issue_s(cls_c, A0, u0, u1);
+            const Pass p_st = p_cur;
+            p_cur = p_nxt;
+            more = next_pass(BlkSeg{}, p_nxt);
+            if (more) cls_n = coords_s(p_nxt.strip, p_nxt.y, B0, B1, B2);  // overlaps with the loads in flight
+            store_s(BlkSeg{}, pass_x(p_st), p_st.y, out);
+            finish_any(cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
         }
-        cls_c = cls_n;
-        read_back(out);              // row yf
-        issue_s(cls_c, A0, u0, u1);  // row yf + RSTEP
-        STAMP(0);
-        const int y_done = yf;
-        yf += RSTEP;
-        more = yf + RSTEP <= y_end;
-        if (more) cls_n = coords_s(yf + RSTEP, B0, B1, B2);  // overlaps with the loads in flight
-        STAMP(1);
-        store_s(y_done, out);
-        STAMP(2);
-        finish_any(cls_c, yf, A0, A1, A2, u0, u1);
-        STAMP(3);
+        read_back(out);
+        store_s(BlkSeg{}, pass_x(p_cur), p_cur.y, out);
     }
-    read_back(out);
-    store_s(yf, out);
-#ifdef BEVWARP_CLOCK
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 4; i++) atomicAdd(&g_clk[4 + i], phase_[i]);
-#endif
 }
 
 // Footprint: mark every in-bounds source pixel any tap would read (measurement aid; exact chain).
@@ -1136,35 +1022,22 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
         }
 }
 
-template <typename T, int C, int INTERP, int MODE>
-void launch_mode(const WarpArgs& a, dim3 grid, hipStream_t stream) {
+template <typename T, int C, int INTERP>
+void launch_tci(const WarpArgs& a, dim3 grid, hipStream_t stream) {
     constexpr bool kRgb8Lin = sizeof(T) == 1 && C == 3 && INTERP == kLinear;
     if constexpr (sizeof(T) == 1) {
         if (a.planar) {
             if (kRgb8Lin && a.src_rs % 4 == 0)
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true, MODE>), grid, dim3(kWG), 0, stream, a);
+                hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true>), grid, dim3(kWG), 0, stream, a);
             else
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true, MODE>), grid, dim3(kWG), 0, stream, a);
+                hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true>), grid, dim3(kWG), 0, stream, a);
             return;
         }
     }
     if (kRgb8Lin && a.src_rs % 4 == 0)
-        hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, false, MODE>), grid, dim3(kWG), 0, stream, a);
+        hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, false>), grid, dim3(kWG), 0, stream, a);
     else
-        hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, false, MODE>), grid, dim3(kWG), 0, stream, a);
-}
-
-template <typename T, int C, int INTERP>
-void launch_tci(const WarpArgs& a, dim3 grid, hipStream_t stream) {
-    if constexpr (has_staged_kernel<T, C, INTERP>()) {
-#ifndef BEVWARP_FORCE_GATHER
-        if (a.src_stage_ok) {
-            launch_mode<T, C, INTERP, kStaged>(a, grid, stream);
-            return;
-        }
-#endif
-    }
-    launch_mode<T, C, INTERP, kGather>(a, grid, stream);
+        hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, false>), grid, dim3(kWG), 0, stream, a);
 }
 
 template <typename T>
@@ -1189,10 +1062,10 @@ void launch_t(const WarpArgs& a, int channels, int interp, dim3 grid, hipStream_
 }  // namespace
 
 #ifdef BEVWARP_CLOCK
-hipError_t debug_read_clock(unsigned long long* out16, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_clk), sizeof(unsigned long long) * 16);
+hipError_t debug_read_clock(unsigned long long* out4, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_clk), sizeof(unsigned long long) * 4);
     if (e == hipSuccess && reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[4] = {0, 0, 0, 0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
     }
     return e;
@@ -1200,7 +1073,18 @@ hipError_t debug_read_clock(unsigned long long* out16, int reset) {
 #endif
 
 int tile_width(int dtype) { return 64 * (dtype == 0 ? pixels_per_lane<uint8_t>() : pixels_per_lane<float>()); }
-int rows_per_pass() { return kWaves; }
+int rows_per_pass() { return kWaves; }  // (a multiple of every format's block height)
+
+// Workgroups of one launch that are resident at the same time: CUs x (waves per SIMD the kernel is compiled for) -- a
+// workgroup is 4 waves, one per SIMD.  The launch geometry is sized against this (bevwarp_api.hip).
+int resident_workgroups(int dtype, int channels, int interp) {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus * waves_per_simd_of(dtype == 0, channels, interp);
+}
 
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream) {
     (void)hipGetLastError();  // a stale error left by the host framework is not this call's

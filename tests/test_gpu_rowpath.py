@@ -20,9 +20,13 @@ def W():
 
 
 def run_gpu(W, src_np, M, dsize, interp, **kw):
-    out = W.warp_perspective(torch.from_numpy(np.ascontiguousarray(src_np)).cuda(), M, dsize, flags=interp, **kw)
+    t = torch.from_numpy(np.ascontiguousarray(src_np)).cuda()
+    poison = torch.full((dsize[1], dsize[0]) + tuple(t.shape[2:]), 77, dtype=t.dtype, device="cuda")  # unwritten pixels must not pass as zeros
+    if "out" not in kw and t.dim() <= 3:
+        kw = dict(kw, out=poison)
+    out = W.warp_perspective(t, M, dsize, flags=interp, **kw)
     torch.cuda.synchronize()
-    return out.cpu().numpy()
+    return out.reshape(poison.shape).cpu().numpy() if out is poison else out.cpu().numpy()
 
 
 def both(W, src, M, dsize, interp, **kw):

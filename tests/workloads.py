@@ -42,6 +42,19 @@ def keystone_inset_H(src_w, src_h, dst_w, dst_h, inset=8.0):
     return homo_from_pts(src, dst)
 
 
+def rotated_H(src_w, src_h, dst_w, dst_h, degrees, zoom=1.2):
+    """A similarity footprint: the BEV window is the frame's centre region turned by `degrees` (source pixels per BEV pixel =
+    `zoom`), small enough to stay inside the frame for every angle.  Measurement aid: row segments of the BEV cross
+    256 * zoom * sin(angle) source rows."""
+    t = np.deg2rad(degrees)
+    c, s = np.cos(t) * zoom, np.sin(t) * zoom
+    # dst -> src: rotate about the BEV centre, land on the frame centre
+    A = np.array([[c, -s, 0.0], [s, c, 0.0], [0, 0, 1.0]])
+    T0 = np.array([[1, 0, -(dst_w - 1) / 2.0], [0, 1, -(dst_h - 1) / 2.0], [0, 0, 1.0]])
+    T1 = np.array([[1, 0, (src_w - 1) / 2.0], [0, 1, (src_h - 1) / 2.0], [0, 0, 1.0]])
+    return np.linalg.inv(T1 @ A @ T0)  # forward map (src -> dst), as warpPerspective callers pass it
+
+
 def jitter_H(H, idx, px=2.0):
     """Per-frame variant: pre-multiply by a seeded +-px translation of the destination."""
     rng = np.random.default_rng(99 + idx)

@@ -9,7 +9,8 @@ Each spec patches a COPY of warp_kernels.hip:
     noblend   finish_s xors the taps instead of blending
     stsmall   stores go to a few KB per frame (no HBM write traffic)
     ldsmall   taps come from the first 64 KB of the frame (cache hits)
-    gather    the launcher never picks the staged kernel
+    notrans   8-bit: pixels stay in registers (no LDS transposition; wrong layout in memory, same work otherwise)
+    notie     no tie-window test in the coordinate chain
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
 import subprocess
@@ -48,8 +49,6 @@ def patch(src, spec):
         rep("    auto read_back = [&](uint4 (&out)[NQ]) {\n", "    auto read_back = [&](uint4 (&out)[NQ]) {\n        if (sizeof(T) == 1) { out[0] = make_uint4(tr_reg[0], tr_reg[1], tr_reg[2], tr_reg[3]); return; }\n")
     elif spec == "notie":
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
-    elif spec == "gather":
-        rep("        if (a.src_stage_ok) {\n            launch_mode<T, C, INTERP, kStaged>", "        if (a.src_stage_ok && a.batch < 0) {\n            launch_mode<T, C, INTERP, kStaged>")
     else:
         raise SystemExit("unknown spec " + spec)
     return src

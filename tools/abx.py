@@ -40,7 +40,11 @@ def main():
     B, (sw, sh), (dw, dh), C = args.batch, args.src, args.dst, args.channels
     tdt, ndt, esz = (torch.uint8, np.uint8, 1) if args.dtype == "u8" else (torch.float32, np.float32, 4)
     interp = 1 if args.interp == "linear" else 0
-    base = {"keystone": wl.keystone_H, "inset": wl.keystone_inset_H, "brno": wl.synth_brno_H}[args.homography](sw, sh, dw, dh)
+    if args.homography.startswith("rot"):  # rot<degrees>[z<zoom>], e.g. rot15 or rot30z0.6
+        deg, _, zoom = args.homography[3:].partition("z")
+        base = wl.rotated_H(sw, sh, dw, dh, float(deg), float(zoom) if zoom else 0.6)
+    else:
+        base = {"keystone": wl.keystone_H, "inset": wl.keystone_inset_H, "brno": wl.synth_brno_H}[args.homography](sw, sh, dw, dh)
     Ms = np.stack([wl.jitter_H(base, g) for g in range(B)])
     minv = warp.device_inverse(Ms, dev)
     set_bytes = B * (sh * sw + dh * dw) * C * esz

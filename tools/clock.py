@@ -44,7 +44,7 @@ while time.time() < t_end:
         warp.warp_perspective(srcs[n % 4], None, (dw, dh), flags=flags, out=dsts[n % 4], M_inv_device=minv)
         n += 1
     torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 4)()
 assert dbg(out, 1) == 0
 for _ in range(20):
     warp.warp_perspective(srcs[n % 4], None, (dw, dh), flags=flags, out=dsts[n % 4], M_inv_device=minv)
@@ -53,6 +53,3 @@ torch.cuda.synchronize()
 assert dbg(out, 0) == 0
 print("%s %s %s: %d workgroups, mean life %.0f shader ticks = %.2f us, clock held %.0f MHz" % (
     args.dtype, args.interp, args.homography, out[2], out[0] / out[2], out[1] / out[2] / 100.0, 100.0 * out[0] / out[1]))
-ph = [out[4 + i] / max(out[2], 1) for i in range(4)]
-print("   row-loop phases of wave 0, ticks per workgroup: read-back + issue loads %.0f | coordinates %.0f | store %.0f | wait + blend %.0f   (sum %.0f)" % (
-    ph[0], ph[1], ph[2], ph[3], sum(ph)))
