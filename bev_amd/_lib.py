@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("BEVWARP_LIB") or os.path.join(_CSRC, "libbevwarp.so")
 
 U8, F32, F64 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/bevwarp.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -33,6 +33,9 @@ SYMBOLS = {
     "bevwarp_project_points": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "bevwarp_rbox_iou": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int,
                                     _c.c_void_p]),
+    "bevwarp_rbox_transform": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
+    "bevwarp_tracker_step": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                        _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
 }
 
 _lib = None

@@ -238,6 +238,47 @@ int bevwarp_project_points(const void* in, void* out, int64_t n, int dim, const 
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
 
+// H / H[2][2] when H is a similarity of the plane in the sense of bev/rbox.py:173-219 (last row ~ (0, 0, 1), equal scale on
+// both axes -- the reference asserts both); scale = sqrt(h00^2 + h10^2)
+static int normalise_similarity(const double* H, double* Hn, double* scale) {
+    if (!H || !finite9(H, 1) || H[8] == 0.0) return BEVWARP_ERR_NOT_FINITE;
+    for (int i = 0; i < 9; i++) Hn[i] = H[i] / H[8];
+    if (fabs(Hn[6]) + fabs(Hn[7]) >= 1e-5) return BEVWARP_ERR_BAD_ARG;
+    const double s0 = sqrt(Hn[0] * Hn[0] + Hn[3] * Hn[3]), s1 = sqrt(Hn[1] * Hn[1] + Hn[4] * Hn[4]);
+    if (!(fabs(s0 - s1) < 1e-5)) return BEVWARP_ERR_BAD_ARG;
+    *scale = s0;
+    return BEVWARP_OK;
+}
+
+int bevwarp_rbox_transform(const void* boxes, int n, int stride, const double* H, int src_is_bev, void* out, int dtype, void* stream) {
+    if (n < 0 || stride < 5 || (n > 0 && (!boxes || !out))) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_F32 && dtype != BEVWARP_F64) return BEVWARP_ERR_UNSUPPORTED;
+    double Hn[9], scale;
+    const int st = normalise_similarity(H, Hn, &scale);
+    if (st != BEVWARP_OK) return st;
+    const hipError_t e = bevwarp::launch_rbox_transform(boxes, n, stride, Hn, scale, src_is_bev != 0, out, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
+int bevwarp_tracker_step(const void* dets_bev, int n, int det_stride, const void* trks_world, int m, int trk_stride, const double* H_world_bev,
+                         const double* H_img_world, double iou_threshold, void* dets_world, void* iou, unsigned char* candidates, void* dets_img,
+                         int dtype, void* stream) {
+    if (n < 0 || m < 0 || det_stride < 5 || trk_stride < 5) return BEVWARP_ERR_BAD_ARG;
+    if (n > 0 && (!dets_bev || !dets_world)) return BEVWARP_ERR_BAD_ARG;
+    if (n > 0 && m > 0 && (!trks_world || !iou || !candidates)) return BEVWARP_ERR_BAD_ARG;
+    if (H_img_world && n > 0 && !dets_img) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_F32 && dtype != BEVWARP_F64) return BEVWARP_ERR_UNSUPPORTED;
+    if (n > 65535) return BEVWARP_ERR_TOO_LARGE;
+    if (!(iou_threshold == iou_threshold)) return BEVWARP_ERR_NOT_FINITE;
+    double Hn[9], scale;
+    const int st = normalise_similarity(H_world_bev, Hn, &scale);
+    if (st != BEVWARP_OK) return st;
+    if (H_img_world && !finite9(H_img_world, 1)) return BEVWARP_ERR_NOT_FINITE;
+    const hipError_t e = bevwarp::launch_tracker_step(dets_bev, n, det_stride, trks_world, m, trk_stride, Hn, scale, H_img_world, iou_threshold, dets_world, iou,
+                                                      candidates, dets_img, dtype, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
 int bevwarp_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype, void* stream) {
     if (na < 0 || nb < 0 || a_stride < 5 || b_stride < 5) return BEVWARP_ERR_BAD_ARG;
     if (na > 0 && nb > 0 && (!a || !b || !out)) return BEVWARP_ERR_BAD_ARG;

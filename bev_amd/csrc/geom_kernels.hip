@@ -124,6 +124,24 @@ __device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B
     return fabs(0.5 * a);
 }
 
+// IoU of box A (cx, cy, w, h, yaw in float64) with the box at pb: circumscribed-circle rejection, then the clip.
+// Boxes whose circumscribed circles are apart cannot intersect: the clip would return exactly 0 for them.  In a tracker
+// step almost every pair ends there, before any sin / cos or clipping (the 1e-4 margin keeps near-touching pairs on the
+// exact path; NaNs fall through to it as well).
+template <typename T>
+__device__ __forceinline__ double pair_iou(const double (&A)[5], const T* __restrict__ pb, double* __restrict__ lds, int tid) {
+    const double bx = (double)pb[0], by = (double)pb[1], bw = (double)pb[2], bh = (double)pb[3];
+    const double dx = A[0] - bx, dy = A[1] - by;
+    const double ra2 = A[2] * A[2] + A[3] * A[3], rb2 = bw * bw + bh * bh;
+    const double rs = 0.5 * (sqrt(ra2) + sqrt(rb2));
+    if (dx * dx + dy * dy > rs * rs * 1.0001 && fabs(A[2] * A[3]) + fabs(bw * bh) > 0) return 0.0;
+    const Quad QA = corners_of(A[0], A[1], A[2], A[3], A[4]);
+    const Quad QB = corners_of(bx, by, bw, bh, (double)pb[4]);
+    const double inter = intersection_area(QA, QB, lds, tid);
+    const double uni = fabs(A[2] * A[3]) + fabs(bw * bh) - inter;
+    return uni > 0 ? inter / uni : 0.0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
@@ -132,24 +150,78 @@ __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restri
     const int i = blockIdx.y;
     if (j >= nb) return;
     const T* pa = a + (int64_t)i * sa;
-    const T* pb = b + (int64_t)j * sb;
-    {   // boxes whose circumscribed circles are apart cannot intersect: the clip below would return exactly 0 for
-        // them.  In a tracker step almost every pair ends here, before any sin / cos or clipping (the 1e-4 margin
-        // keeps near-touching pairs on the exact path; NaNs fall through to it as well).
-        const double dx = (double)pa[0] - (double)pb[0], dy = (double)pa[1] - (double)pb[1];
-        const double ra2 = (double)pa[2] * (double)pa[2] + (double)pa[3] * (double)pa[3];
-        const double rb2 = (double)pb[2] * (double)pb[2] + (double)pb[3] * (double)pb[3];
-        const double rs = 0.5 * (sqrt(ra2) + sqrt(rb2));
-        if (dx * dx + dy * dy > rs * rs * 1.0001 && fabs((double)pa[2] * (double)pa[3]) + fabs((double)pb[2] * (double)pb[3]) > 0) {
-            out[(int64_t)i * nb + j] = (T)0.0;
-            return;
+    const double A[5] = {(double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]};
+    out[(int64_t)i * nb + j] = (T)pair_iou<T>(A, b + (int64_t)j * sb, s_poly, (int)threadIdx.x);
+}
+
+// ---- rotated boxes through a similarity H (reference bev/rbox.py:173-219) ------------------------------------------
+// H is normalised (h[8] = 1) and affine (h[6], h[7] ~ 0: the host checks); scale = sqrt(h00^2 + h10^2) (dist_world_bev).
+struct SimH {
+    double h[9];
+    double scale;
+};
+template <typename T>
+__device__ __forceinline__ void box_through(const T* __restrict__ p, const SimH& H, int src_is_bev, double (&o)[5]) {
+    const double x = (double)p[0], y = (double)p[1], r = (double)p[4];
+    // yaw2v (rbox.py:28-36): a BEV yaw is measured from the v axis (sin, cos), a world yaw from the x axis (cos, sin);
+    // angle_world_bev pushes that direction through H and reads it back in the TARGET's convention (v2yaw, :20-27)
+    double sn, cs;
+    sincos(r, &sn, &cs);
+    const double vx = src_is_bev ? sn : cs, vy = src_is_bev ? cs : sn;
+    const double tx = H.h[0] * vx + H.h[1] * vy, ty = H.h[3] * vx + H.h[4] * vy;
+    o[4] = src_is_bev ? atan2(ty, tx) : atan2(tx, ty);
+    const double X = H.h[0] * x + H.h[1] * y + H.h[2], Y = H.h[3] * x + H.h[4] * y + H.h[5], W = H.h[6] * x + H.h[7] * y + H.h[8];
+    o[0] = X / W;  // pts_world_bev (rbox.py:136-151)
+    o[1] = Y / W;
+    o[2] = (double)p[2] * H.scale;  // dist_world_bev (:153-160)
+    o[3] = (double)p[3] * H.scale;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rbox_transform_kernel(const T* __restrict__ in, int n, int stride, const SimH H, int src_is_bev, T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double o[5];
+    box_through<T>(in + (int64_t)i * stride, H, src_is_bev, o);
+#pragma unroll
+    for (int k = 0; k < 5; k++) out[(int64_t)i * 5 + k] = (T)o[k];
+}
+
+// ---- one tracker step in one launch (reference bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 with the association
+// front-end of bev/tracker/rbox_tracker.py:383-405): block (jb, i) moves detection i from the BEV raster to the world
+// (thread 0, shared through LDS), scores it against 256 predicted tracker boxes, and writes the IoU row segment and the
+// `iou > threshold` gate; block (0, i) also writes the world box and its image-plane centre (rbox_world_img, rbox.py:221-226).
+template <typename T>
+__global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __restrict__ dets, int n, int sd, const T* __restrict__ trks, int m, int st,
+                                                                   const SimH Hwb, const H9 Him, int has_img, double thr, T* __restrict__ dets_world,
+                                                                   T* __restrict__ iou, uint8_t* __restrict__ cand, T* __restrict__ dets_img) {
+    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];
+    __shared__ double s_box[5];
+    const int i = blockIdx.y, tid = (int)threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + tid;
+    if (tid == 0) {
+        double o[5];
+        box_through<T>(dets + (int64_t)i * sd, Hwb, 1, o);
+#pragma unroll
+        for (int k = 0; k < 5; k++) s_box[k] = o[k];
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) dets_world[(int64_t)i * 5 + k] = (T)o[k];
+            if (has_img) {
+                const double X = Him.h[0] * o[0] + Him.h[1] * o[1] + Him.h[2], Y = Him.h[3] * o[0] + Him.h[4] * o[1] + Him.h[5];
+                const double W = Him.h[6] * o[0] + Him.h[7] * o[1] + Him.h[8];
+                dets_img[(int64_t)i * 2] = (T)(X / W);
+                dets_img[(int64_t)i * 2 + 1] = (T)(Y / W);
+            }
         }
     }
-    const Quad A = corners_of((double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]);
-    const Quad B = corners_of((double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]);
-    const double inter = intersection_area(A, B, s_poly, (int)threadIdx.x);
-    const double uni = fabs((double)pa[2] * (double)pa[3]) + fabs((double)pb[2] * (double)pb[3]) - inter;
-    out[(int64_t)i * nb + j] = (T)(uni > 0 ? inter / uni : 0.0);
+    __syncthreads();
+    if (j >= m) return;
+    // (the box the tracker would see: rounded to the storage type like the dets_world output)
+    const double A[5] = {(double)(T)s_box[0], (double)(T)s_box[1], (double)(T)s_box[2], (double)(T)s_box[3], (double)(T)s_box[4]};
+    const double v = pair_iou<T>(A, trks + (int64_t)j * st, s_poly, tid);
+    iou[(int64_t)i * m + j] = (T)v;
+    cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);
 }
 
 // ---- alpha composite (reference bev/tool/compo.py:16-23) ------------------------------------------------
@@ -221,6 +293,45 @@ hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, i
         hipLaunchKernelGGL(rbox_iou_kernel<double>, grid, block, 0, stream, (const double*)a, na, a_stride, (const double*)b, nb, b_stride, (double*)out);
     else
         hipLaunchKernelGGL(rbox_iou_kernel<float>, grid, block, 0, stream, (const float*)a, na, a_stride, (const float*)b, nb, b_stride, (float*)out);
+    return hipGetLastError();
+}
+
+namespace {
+SimH make_sim(const double* H, double scale) {
+    SimH s;
+    for (int i = 0; i < 9; i++) s.h[i] = H[i];
+    s.scale = scale;
+    return s;
+}
+}  // namespace
+
+hipError_t launch_rbox_transform(const void* in, int n, int stride, const double* H, double scale, int src_is_bev, void* out, int dtype, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const SimH s = make_sim(H, scale);
+    const dim3 block(256), grid((n + 255) / 256);
+    if (dtype == 2)
+        hipLaunchKernelGGL(rbox_transform_kernel<double>, grid, block, 0, stream, (const double*)in, n, stride, s, src_is_bev, (double*)out);
+    else
+        hipLaunchKernelGGL(rbox_transform_kernel<float>, grid, block, 0, stream, (const float*)in, n, stride, s, src_is_bev, (float*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tracker_step(const void* dets, int n, int det_stride, const void* trks, int m, int trk_stride, const double* H_world_bev, double scale,
+                               const double* H_img_world, double iou_threshold, void* dets_world, void* iou, unsigned char* cand, void* dets_img,
+                               int dtype, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const SimH s = make_sim(H_world_bev, scale);
+    H9 him;
+    for (int i = 0; i < 9; i++) him.h[i] = H_img_world ? H_img_world[i] : 0.0;
+    const dim3 block(kIouThreads), grid(m > 0 ? (m + kIouThreads - 1) / kIouThreads : 1, n);
+    if (dtype == 2)
+        hipLaunchKernelGGL(tracker_step_kernel<double>, grid, block, 0, stream, (const double*)dets, n, det_stride, (const double*)trks, m, trk_stride, s, him,
+                           H_img_world != nullptr, iou_threshold, (double*)dets_world, (double*)iou, cand, (double*)dets_img);
+    else
+        hipLaunchKernelGGL(tracker_step_kernel<float>, grid, block, 0, stream, (const float*)dets, n, det_stride, (const float*)trks, m, trk_stride, s, him,
+                           H_img_world != nullptr, iou_threshold, (float*)dets_world, (float*)iou, cand, (float*)dets_img);
     return hipGetLastError();
 }
 

@@ -42,4 +42,9 @@ hipError_t launch_composite(const uint8_t* bg, const uint8_t* fg, const uint8_t*
 hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype,
                            hipStream_t stream);
 
+hipError_t launch_rbox_transform(const void* in, int n, int stride, const double* H, double scale, int src_is_bev, void* out, int dtype, hipStream_t stream);
+hipError_t launch_tracker_step(const void* dets, int n, int det_stride, const void* trks, int m, int trk_stride, const double* H_world_bev, double scale,
+                               const double* H_img_world, double iou_threshold, void* dets_world, void* iou, unsigned char* cand, void* dets_img,
+                               int dtype, hipStream_t stream);
+
 }  // namespace bevwarp

@@ -1,57 +1,77 @@
-"""Batched tracker geometry as one device step.
+"""Batched tracker geometry as ONE device launch.
 
-The reference's per-frame tracking loop (bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 with the association
-front-end of bev/tracker/rbox_tracker.py:383-405) moves detections from the BEV raster to the world plane
-(`rbox_world_bev`), scores them against the trackers' predicted boxes (`iou_batch_rbox` -> d3d), thresholds the
-scores, and projects box centres into the image (`rbox_world_img`).  Those are tens of numpy calls per frame on
-tens of boxes; here they are a handful of launches on device tensors with no host synchronisation: the homography
-is validated on the host once, boxes stay on the GPU, the IoU matrix comes from the HIP kernel.  The Hungarian
-assignment and the per-track Kalman filters stay on the host (out of scope)."""
+The reference's per-frame tracking loop (bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 with the association front-end of
+bev/tracker/rbox_tracker.py:383-405) moves detections from the BEV raster to the world plane (`rbox_world_bev`), scores
+them against the trackers' predicted boxes (`iou_batch_rbox` -> d3d), thresholds the scores, and projects box centres into
+the image (`rbox_world_img`): tens of numpy calls per frame.  Here that is `bevwarp_tracker_step` -- one HIP launch on
+device tensors, no host synchronisation, nothing computed by torch ops.  The Hungarian assignment and the per-track Kalman
+filters stay on the host (out of scope)."""
+import ctypes
+
 import numpy as np
 import torch
 
-from .iou import rbox_iou
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 
 
-def _similarity_terms(H):
-    """Host-side checks and constants of rbox_world_bev (rbox.py:173-219): H must be a similarity."""
-    H = np.asarray(H, dtype=np.float64)
-    H = H / H[2, 2]
-    assert abs(H[2, 0]) + abs(H[2, 1]) < 1e-5, "H must be affine (a similarity between the BEV raster and the world)"
-    scale, scale_1 = np.hypot(H[0, 0], H[0, 1]), np.hypot(H[1, 0], H[1, 1])
-    assert abs(scale - scale_1) < 1e-5, "H must scale both axes equally"
-    return H, float(scale)
+def _host9(H):
+    return np.ascontiguousarray(np.asarray(H, dtype=np.float64).reshape(3, 3))
+
+
+def _dev(x, device):
+    return x.to(device) if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+def _boxes(t, what):
+    if t.dim() != 2 or t.shape[1] < 5 or t.dtype not in _DTYPES:
+        raise ValueError("%s must be an (n, >=5) float32 / float64 tensor, got %s %s" % (what, tuple(t.shape), t.dtype))
+    return t.contiguous()
 
 
 def rbox_world_bev_device(rbox_src, H, src):
     """(n, >=5) CUDA tensor of [x, y, w, h, yaw] between the BEV ("bev": yaw = atan2(u, v)) and the world ("world":
-    yaw = atan2(y, x)) through the similarity H -- rbox.py:173-219 / rbox_torch.py:123-168 without their device->host
-    assertions.  Returns (n, 5)."""
+    yaw = atan2(y, x)) through the similarity H -- rbox.py:173-219 / rbox_torch.py:123-168 in one launch
+    (bevwarp_rbox_transform).  Raises ValueError when H is not a similarity (the reference's assertions).  Returns (n, 5)."""
     assert src in ("bev", "world")
-    H, scale = _similarity_terms(H)
-    r = rbox_src[:, 4]
-    # yaw2v (rbox.py:20-36): bev yaw is measured from the v axis, world yaw from the x axis
-    vx, vy = (torch.sin(r), torch.cos(r)) if src == "bev" else (torch.cos(r), torch.sin(r))
-    tx = H[0, 0] * vx + H[0, 1] * vy
-    ty = H[1, 0] * vx + H[1, 1] * vy
-    r_tgt = torch.atan2(ty, tx) if src == "bev" else torch.atan2(tx, ty)  # v2yaw of the TARGET convention
-    x, y = rbox_src[:, 0], rbox_src[:, 1]
-    return torch.stack([H[0, 0] * x + H[0, 1] * y + H[0, 2], H[1, 0] * x + H[1, 1] * y + H[1, 2],
-                        rbox_src[:, 2] * scale, rbox_src[:, 3] * scale, r_tgt], dim=1)
+    if not isinstance(rbox_src, torch.Tensor) or not rbox_src.is_cuda:
+        raise ValueError("rbox_world_bev_device needs a CUDA (HIP) tensor; bev.rbox.rbox_world_bev is the host version")
+    b = _boxes(rbox_src, "rbox_src")
+    out = torch.empty((b.shape[0], 5), dtype=b.dtype, device=b.device)
+    Hh = _host9(H)
+    stream = torch.cuda.current_stream(b.device).cuda_stream
+    with torch.cuda.device(b.device):
+        st = _lib.load().bevwarp_rbox_transform(b.data_ptr(), b.shape[0], b.shape[1], Hh.ctypes.data_as(ctypes.c_void_p), int(src == "bev"),
+                                                out.data_ptr(), _DTYPES[b.dtype], ctypes.c_void_p(stream))
+    _lib.check(st)
+    return out
 
 
-def tracker_geometry_step(dets_bev, trks_world, H_world_bev, iou_threshold=0.3, H_img_world=None, device="cuda"):
-    """dets_bev (n, >=5) detections in BEV pixels, trks_world (m, >=5) predicted tracker boxes in the world.
-    Returns a dict of device tensors: dets_world (n, 5), iou (n, m), candidates (n, m) bool = iou > iou_threshold
-    (the gate of rbox_tracker.py:395-405), and, when H_img_world is given, dets_img (n, 2) image pixels of the box
-    centres (rbox_world_img, rbox.py:221-226).  No host synchronisation."""
-    def dev(x):
-        return x.to(device) if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x)).to(device)
-    dets_bev, trks_world = dev(dets_bev), dev(trks_world)
-    dets_world = rbox_world_bev_device(dets_bev, H_world_bev, "bev")
-    iou = rbox_iou(dets_world, trks_world[:, :5].to(dets_world.dtype))
-    out = {"dets_world": dets_world, "iou": iou, "candidates": iou > iou_threshold}
-    if H_img_world is not None:
-        from .points import project_points
-        out["dets_img"] = project_points(dets_world[:, :2].contiguous(), H_img_world)
+def tracker_geometry_step(dets_bev, trks_world, H_world_bev, iou_threshold=0.3, H_img_world=None, device="cuda", out=None):
+    """dets_bev (n, >=5) detections in BEV pixels, trks_world (m, >=5) predicted tracker boxes in the world (numpy or
+    tensors; float64 unless both are float32 tensors).  Returns a dict of device tensors: dets_world (n, 5), iou (n, m),
+    candidates (n, m) bool = iou > iou_threshold (the gate of rbox_tracker.py:395-405), and, when H_img_world is given,
+    dets_img (n, 2) image pixels of the box centres (rbox_world_img, rbox.py:221-226).  One launch, no host synchronisation.
+    `out`: a dict returned by an earlier call with the same shapes, to reuse its tensors (e.g. inside a captured graph)."""
+    d, t = _dev(dets_bev, device), _dev(trks_world, device)
+    if d.dtype != t.dtype:
+        d, t = d.to(torch.float64), t.to(torch.float64)
+    d, t = _boxes(d, "dets_bev"), _boxes(t, "trks_world")
+    n, m = d.shape[0], t.shape[0]
+    if out is None:
+        out = {"dets_world": torch.empty((n, 5), dtype=d.dtype, device=d.device), "iou": torch.empty((n, m), dtype=d.dtype, device=d.device),
+               "candidates": torch.empty((n, m), dtype=torch.bool, device=d.device)}
+        if H_img_world is not None:
+            out["dets_img"] = torch.empty((n, 2), dtype=d.dtype, device=d.device)
+    Hwb = _host9(H_world_bev)
+    Him = None if H_img_world is None else _host9(H_img_world)
+    stream = torch.cuda.current_stream(d.device).cuda_stream
+    with torch.cuda.device(d.device):
+        st = _lib.load().bevwarp_tracker_step(
+            d.data_ptr(), n, d.shape[1], t.data_ptr(), m, t.shape[1], Hwb.ctypes.data_as(ctypes.c_void_p),
+            None if Him is None else Him.ctypes.data_as(ctypes.c_void_p), float(iou_threshold), out["dets_world"].data_ptr(),
+            out["iou"].data_ptr(), out["candidates"].data_ptr(), out["dets_img"].data_ptr() if Him is not None else None,
+            _DTYPES[d.dtype], ctypes.c_void_p(stream))
+    _lib.check(st)
     return out

@@ -18,6 +18,13 @@
  *                             Calib.gen_center_in_world, bev/calib.py:135-138
  *   bevwarp_rbox_iou        iou_batch_rbox -> d3d.box.box2d_iou(.., method="rbox"),
  *                             bev/tracker/rbox_tracker.py:87-92 (call site :393-394)
+ *   bevwarp_rbox_transform  rbox_world_bev(rbox_src, H, src), bev/rbox.py:173-219 (yaw conventions :20-36)
+ *   bevwarp_tracker_step    one frame of bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 up to the assignment: detections
+ *                             BEV -> world (rbox_world_bev), IoU against the trackers' predicted boxes (iou_batch_rbox),
+ *                             the `iou > iou_threshold` gate of associate_detections_to_trackers
+ *                             (bev/tracker/rbox_tracker.py:383-405) and the image-plane centres (rbox_world_img,
+ *                             bev/rbox.py:221-226) -- ONE launch; the Hungarian assignment and the Kalman filters stay
+ *                             on the host
  *
  * Conventions
  *   - Plain C: pointers, sizes, enums.  No torch / HIP types in signatures (`stream` is a hipStream_t
@@ -38,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BEVWARP_ABI_VERSION 2
+#define BEVWARP_ABI_VERSION 3
 
 typedef enum bevwarp_status {
     BEVWARP_OK = 0,
@@ -130,6 +137,31 @@ int bevwarp_project_points(const void *in, void *out, int64_t n, int dim, const 
  */
 int bevwarp_rbox_iou(const void *a, int na, int a_stride, const void *b, int nb, int b_stride, void *out, int dtype,
                      void *stream);
+
+/*
+ * out[i] = rbox_world_bev(boxes[i], H, src): rows [x, y, w, h, yaw, ...] (`stride` values per row, >= 5) through the
+ * similarity H (HOST, 9 doubles; normalised by H[8]; BEVWARP_ERR_BAD_ARG when its last row is not (0, 0, 1) to 1e-5 or its
+ * axes scale differently, the two conditions the reference asserts).  src_is_bev != 0: rows are BEV boxes (yaw from the
+ * v axis), out rows are world boxes (yaw from the x axis); 0: the other way round.  out is n x 5, same dtype
+ * (BEVWARP_F32 | BEVWARP_F64, arithmetic float64).
+ */
+int bevwarp_rbox_transform(const void *boxes, int n, int stride, const double *H /*HOST*/, int src_is_bev, void *out,
+                           int dtype, void *stream);
+
+/*
+ * One tracker step, one launch:
+ *   dets_world[i]     = rbox_world_bev(dets_bev[i], H_world_bev, "bev")                         n x 5
+ *   iou[i][j]         = IoU(dets_world[i], trks_world[j])         (as bevwarp_rbox_iou)         n x m
+ *   candidates[i][j]  = iou[i][j] > iou_threshold                 (uint8 0 / 1)                 n x m
+ *   dets_img[i]       = dehomogenise(H_img_world @ (dets_world[i].xy, 1))   when H_img_world    n x 2
+ * dets_bev rows have det_stride >= 5 values, trks_world rows trk_stride >= 5 (a tracker's state row may carry more).
+ * H_world_bev as in bevwarp_rbox_transform; H_img_world (HOST, 9 doubles) may be NULL (then dets_img is not touched).
+ * m == 0 is allowed (only dets_world / dets_img are produced).  n <= 65535.
+ */
+int bevwarp_tracker_step(const void *dets_bev, int n, int det_stride, const void *trks_world, int m, int trk_stride,
+                         const double *H_world_bev /*HOST*/, const double *H_img_world /*HOST, may be NULL*/,
+                         double iou_threshold, void *dets_world, void *iou, unsigned char *candidates, void *dets_img,
+                         int dtype, void *stream);
 
 #ifdef __cplusplus
 }

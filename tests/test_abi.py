@@ -33,13 +33,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert getattr(raw, n) is not None
-    assert lib.bevwarp_version() == _lib.ABI_VERSION == 2
+    assert lib.bevwarp_version() == _lib.ABI_VERSION == 3
 
 
 def test_header_cites_the_reference_interfaces():
     with open(os.path.join(ROOT, "include", "bevwarp.h")) as f:
         text = f.read()
-    for cite in ("vis_homo.py:89", "bev/tool/compo.py:38", "bev/rbox.py:136-151", "bev/tracker/rbox_tracker.py:87-92"):
+    for cite in ("vis_homo.py:89", "bev/tool/compo.py:38", "bev/rbox.py:136-151", "bev/tracker/rbox_tracker.py:87-92", "bev/rbox.py:173-219",
+                 "bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109", "bev/tracker/rbox_tracker.py:383-405"):
         assert cite in text
 
 
@@ -111,3 +112,33 @@ def test_product_package_never_imports_the_oracle():
                     with open(os.path.join(dirpath, fn)) as f:
                         src = f.read()
                     assert "cpu_oracle" not in src and "liboracle" not in src and "from oracle" not in src, os.path.join(dirpath, fn)
+
+
+def test_tracker_step_validates_before_touching_the_device(lib):
+    one = ctypes.c_void_p(16)
+    eye = np.eye(3)
+    H = eye.ctypes.data_as(ctypes.c_void_p)
+    step = lib.bevwarp_tracker_step
+    ok = [one, 4, 5, one, 3, 7, H, None, 0.3, one, one, one, None, _lib.F64, None]
+
+    def call(**patch):
+        a = list(ok)
+        for k, v in patch.items():
+            a[int(k[1:])] = v
+        return step(*a)
+
+    assert call(a2=4) == -1                       # fewer than 5 values per detection row
+    assert call(a0=None) == -1                    # null detections
+    assert call(a10=None) == -1                   # m > 0 without an IoU buffer
+    assert call(a13=_lib.U8) == -2                # dtype
+    assert call(a1=70000) == -3                   # n > 65535
+    shear = np.array([[1.0, 0, 0], [0, 2.0, 0], [0, 0, 1]])
+    assert call(a6=shear.ctypes.data_as(ctypes.c_void_p)) == -1       # axes scale differently
+    proj = np.array([[1.0, 0, 0], [0, 1.0, 0], [1e-3, 0, 1]])
+    assert call(a6=proj.ctypes.data_as(ctypes.c_void_p)) == -1        # not affine
+    nan = np.full((3, 3), np.nan)
+    assert call(a6=nan.ctypes.data_as(ctypes.c_void_p)) == -4
+    assert call(a7=eye.ctypes.data_as(ctypes.c_void_p)) == -1         # image centres asked for, no buffer
+    assert call(a1=0) == 0                        # nothing to do: no launch, no device
+    assert lib.bevwarp_rbox_transform(one, 0, 5, H, 1, one, _lib.F64, None) == 0
+    assert lib.bevwarp_rbox_transform(one, 3, 4, H, 1, one, _lib.F64, None) == -1

@@ -102,36 +102,105 @@ def test_composite_bev_img_matches_reference_arithmetic(golden):
     assert got.shape == (640, 320, 3) and got.dtype == torch.uint8
 
 
-def test_tracker_geometry_step_matches_host_functions():
-    """detections BEV -> world, IoU against predicted tracker boxes, gating and image centres as
-    one device step == the host functions that are pinned by the reference's own vectors (rbox_world_bev,
-    pts_world_bev) and the IoU oracle."""
+def _tracker_case(n, m, seed=21):
     import bev
     from bev_amd import rbox as host_rbox
-    from bev_amd.tracker_geom import rbox_world_bev_device, tracker_geometry_step
     calib = bev.Calib(vp1=np.array([1200.0, -300.0]), vp2=np.array([-2500.0, -150.0]), pp=np.array([959.5, 539.5]), height=8, u_size=1920, v_size=1080)
     center = calib.gen_center_in_world()
-    bspec = bev.BEVWorldSpec(u_size=512, v_size=512, u_axis="y", v_axis="-x", x_size=64, y_size=64, x_min=center[0] - 20, y_min=center[1] - 32)
+    bspec = bev.BEVWorldSpec(u_size=1024, v_size=1024, u_axis="y", v_axis="-x", x_size=64, y_size=64, x_min=center[0] - 20, y_min=center[1] - 32)
     H_world_bev = bspec.gen_H_world_bev()
     H_img_world = np.linalg.inv(calib.gen_H_world_img())
-    rng = np.random.default_rng(21)
-    n, m = 300, 257
-    dets_bev = np.column_stack([rng.uniform(0, 512, (n, 2)), rng.uniform(12, 18, n), rng.uniform(28, 48, n), rng.uniform(-np.pi, np.pi, n)])
-    dets_world_host = host_rbox.rbox_world_bev(dets_bev, H_world_bev, "bev")
-    # trackers: the detections' own world boxes, jittered (so a band of pairs overlaps), plus strays
-    trks = np.vstack([dets_world_host[:200] + rng.normal(0, [0.4, 0.4, 0.05, 0.1, 0.05], (200, 5)),
-                      np.column_stack([rng.uniform(-30, 60, (57, 2)), rng.uniform(1.6, 2.2, 57), rng.uniform(3.5, 6, 57), rng.uniform(-np.pi, np.pi, 57)])])
+    rng = np.random.default_rng(seed)
+    dets_bev = np.column_stack([rng.uniform(0, 1024, (n, 2)), rng.uniform(24, 36, n), rng.uniform(56, 96, n), rng.uniform(-np.pi, np.pi, n)])
+    dets_world_host = host_rbox.rbox_world_bev(dets_bev, H_world_bev, "bev") if n else np.zeros((0, 5))
+    # trackers: the detections' own world boxes, jittered (so a band of pairs overlaps), plus strays; rows carry the
+    # tracker's extra state columns (velocity, id) like the reference's `trackers` array
+    k = min(n, (2 * m) // 3)
+    near = dets_world_host[:k] + rng.normal(0, [0.4, 0.4, 0.05, 0.1, 0.05], (k, 5))
+    far = np.column_stack([rng.uniform(-30, 60, (m - k, 2)), rng.uniform(1.6, 2.2, m - k), rng.uniform(3.5, 6, m - k), rng.uniform(-np.pi, np.pi, m - k)])
+    trks = np.column_stack([np.vstack([near, far]), rng.normal(0, 1, (m, 2))])
+    return dets_bev, trks, dets_world_host, H_world_bev, H_img_world
+
+
+@pytest.mark.parametrize("n,m", [(512, 512), (300, 257), (1, 1), (7, 0), (0, 5)])
+def test_tracker_step_one_launch_matches_host_functions(n, m):
+    """SURVEY.md 8(f4) at configs[4]'s size: detections BEV -> world, IoU against predicted tracker boxes, the gate and the
+    image centres from ONE launch == the host functions that the reference's own vectors pin (rbox_world_bev,
+    pts_world_bev) and the IoU oracle."""
+    from bev_amd import rbox as host_rbox
+    from bev_amd.tracker_geom import rbox_world_bev_device, tracker_geometry_step
+    dets_bev, trks, dets_world_host, H_world_bev, H_img_world = _tracker_case(n, m)
     out = tracker_geometry_step(dets_bev, trks, H_world_bev, iou_threshold=0.3, H_img_world=H_img_world)
+    assert out["dets_world"].shape == (n, 5) and out["iou"].shape == (n, m) and out["candidates"].dtype == torch.bool
+    if n == 0:
+        return
     np.testing.assert_allclose(out["dets_world"].cpu().numpy(), dets_world_host, rtol=1e-12, atol=1e-12)
-    exp_iou = co.rbox_iou(out["dets_world"].cpu().numpy(), trks)
-    np.testing.assert_allclose(out["iou"].cpu().numpy(), exp_iou, rtol=0, atol=1e-12)
-    assert (exp_iou > 0.3).sum() > 100
-    np.testing.assert_array_equal(out["candidates"].cpu().numpy(), out["iou"].cpu().numpy() > 0.3)
     np.testing.assert_allclose(out["dets_img"].cpu().numpy(), host_rbox.rbox_world_img(dets_world_host, H_img_world), rtol=1e-10, atol=1e-8)
-    # and back: world -> bev is the inverse map
+    if m:
+        exp_iou = co.rbox_iou(out["dets_world"].cpu().numpy(), trks[:, :5])
+        np.testing.assert_allclose(out["iou"].cpu().numpy(), exp_iou, rtol=0, atol=1e-12)
+        if n >= 300:
+            assert (exp_iou > 0.3).sum() > 100
+        np.testing.assert_array_equal(out["candidates"].cpu().numpy(), out["iou"].cpu().numpy() > 0.3)
+    # and back: world -> bev is the inverse map (bevwarp_rbox_transform, both directions)
     back = rbox_world_bev_device(out["dets_world"], np.linalg.inv(H_world_bev), "world").cpu().numpy()
-    np.testing.assert_allclose(back[:, :4], dets_bev[:, :4], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(back[:, :4], dets_bev[:, :4], rtol=1e-9, atol=1e-8)
     np.testing.assert_allclose(np.angle(np.exp(1j * (back[:, 4] - dets_bev[:, 4]))), 0, atol=1e-9)
+    np.testing.assert_allclose(rbox_world_bev_device(torch.from_numpy(dets_bev).cuda(), H_world_bev, "bev").cpu().numpy(), dets_world_host, rtol=1e-12, atol=1e-12)
+
+
+def test_tracker_step_float32_and_argument_errors():
+    from bev_amd.tracker_geom import rbox_world_bev_device, tracker_geometry_step
+    dets_bev, trks, dets_world_host, H_world_bev, H_img_world = _tracker_case(64, 48, seed=5)
+    out = tracker_geometry_step(torch.from_numpy(dets_bev).float().cuda(), torch.from_numpy(trks).float().cuda(), H_world_bev, 0.25, H_img_world)
+    assert out["iou"].dtype == torch.float32
+    np.testing.assert_allclose(out["dets_world"].cpu().numpy(), dets_world_host, rtol=2e-6, atol=2e-5)
+    exp_iou = co.rbox_iou(out["dets_world"].double().cpu().numpy(), trks[:, :5].astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(out["iou"].cpu().numpy(), exp_iou, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(out["candidates"].cpu().numpy(), out["iou"].cpu().numpy() > np.float32(0.25))
+    # H must be a similarity (the reference asserts it): a projective last row and unequal axis scales are refused
+    bad = H_world_bev.copy()
+    bad[2, 0] = 1e-3
+    with pytest.raises(ValueError):
+        tracker_geometry_step(dets_bev, trks, bad)
+    with pytest.raises(ValueError):
+        rbox_world_bev_device(torch.from_numpy(dets_bev).cuda(), np.diag([1.0, 2.0, 1.0]), "bev")
+    with pytest.raises(ValueError):
+        tracker_geometry_step(dets_bev[:, :4], trks, H_world_bev)
+
+
+def test_config5_full_step_eager_and_graphed():
+    """BASELINE.json configs[4] as one per-camera step: 1080p -> 1024^2 uint8 BEV warp + the tracker launch on 512 x 512
+    boxes, launched eagerly and replayed from a captured graph on new frames / boxes."""
+    from bev_amd import warp as W
+    from bev_amd.graph import GraphedStep
+    from bev_amd.tracker_geom import tracker_geometry_step
+    from tests import workloads as wl
+    n = m = 512
+    dets_bev, trks, dets_world_host, H_world_bev, H_img_world = _tracker_case(n, m, seed=3)
+    M = wl.synth_brno_H(1920, 1080, 1024, 1024)
+    src = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda")
+    bev_img = torch.empty((1024, 1024, 3), dtype=torch.uint8, device="cuda")
+    minv = W.device_inverse(M, src.device)
+    d_dev, t_dev = torch.zeros((n, 5), dtype=torch.float64, device="cuda"), torch.zeros((m, 7), dtype=torch.float64, device="cuda")
+    res = tracker_geometry_step(d_dev, t_dev, H_world_bev, 0.3, H_img_world)  # allocates the outputs once
+
+    def step():
+        W.warp_perspective(src, None, (1024, 1024), out=bev_img, M_inv_device=minv)
+        return tracker_geometry_step(d_dev, t_dev, H_world_bev, 0.3, H_img_world, out=res)
+
+    g = GraphedStep(step)
+    for i, mode in enumerate(["eager", "graph", "graph"]):
+        f = wl.frame(30 + i, 1080, 1920, np.uint8)
+        db, tk, dw_host, _, _ = _tracker_case(n, m, seed=40 + i)
+        src.copy_(torch.from_numpy(f).cuda())
+        d_dev.copy_(torch.from_numpy(db).cuda())
+        t_dev.copy_(torch.from_numpy(tk).cuda())
+        out = step() if mode == "eager" else g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(bev_img.cpu().numpy(), co.warp_perspective(f, M, (1024, 1024), 1, nthreads=8))
+        np.testing.assert_allclose(out["dets_world"].cpu().numpy(), dw_host, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out["iou"].cpu().numpy(), co.rbox_iou(out["dets_world"].cpu().numpy(), tk[:, :5]), rtol=0, atol=1e-12)
 
 
 def test_composite_reg_img_matches_numpy_expression():
