@@ -1,9 +1,15 @@
 """Device composites: the second in-repo caller of the warp (reference bev/tool/compo.py:5-49).
 
-composite_reg_img   alpha blend  fg * m + bg * (1 - m), m = mask / 255, rounded and clipped to uint8 (compo.py:5-24)
-composite_bev_img   warp background, foreground and mask into the BEV (three warps through the HIP path) and blend
-                    (compo.py:26-49).  All pixels stay on the GPU; the blend is one HIP launch in float64 like the reference
-                    (bevwarp_composite).
+composite_reg_img   alpha blend  fg * m + bg * (1 - m), m = mask / 255, rounded and clipped to uint8 (compo.py:5-24):
+                    one HIP launch in float64 like the reference's numpy expression (bevwarp_composite)
+composite_bev_img   background, foreground and mask warped into the BEV and blended (compo.py:26-49) in ONE launch
+                    (bevwarp_warp_composite): every BEV pixel samples the background through H_img2bev_fix and the
+                    foreground + its mask through H_img2bev_cam and blends in registers; no warped image is ever written.
+                    Bit-identical to three bevwarp_warp calls followed by bevwarp_composite.
+
+Both take numpy arrays or CUDA tensors (uint8, HWC).  Like the reference they return numpy when every image came in as
+numpy; when any image is a tensor the result stays on the device.  Image paths are not accepted (the reference reads them
+with cv2.imread: decoding is outside this path).
 """
 import ctypes
 
@@ -12,44 +18,73 @@ import torch
 
 from . import _lib
 from .homo import homo_from_KRt
-from .warp import warp_perspective
+from .warp import device_inverse
 
 
 def _as_cuda(img, device):
+    if isinstance(img, str):
+        raise ValueError("image paths are not supported: decode the file and pass the array (the reference uses cv2.imread)")
     if isinstance(img, torch.Tensor):
         return img.to(device)
     return torch.from_numpy(np.ascontiguousarray(img)).to(device)
 
 
+def _hwc(t):
+    if t.dtype != torch.uint8 or t.dim() not in (2, 3):
+        raise ValueError("images must be uint8 (H, W) or (H, W, C), got %s %s" % (tuple(t.shape), t.dtype))
+    t = t if t.dim() == 3 else t[:, :, None]
+    return t if (t.stride(2) == 1 and t.stride(1) == t.shape[2]) else t.contiguous()
+
+
+def gray_bgr(fg):
+    """cv2.cvtColor(cv2.cvtColor(fg, COLOR_BGR2GRAY), COLOR_GRAY2BGR) for uint8 BGR (the reference's bw_mode, compo.py:13-14):
+    OpenCV's 14-bit fixed point, gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, replicated to three channels.
+    (Restated from OpenCV's color conversion; parity unpinned -- the reference holds no fixture for it.)"""
+    f = fg.to(torch.int32)
+    g = ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).to(torch.uint8)
+    return g[..., None].expand(-1, -1, 3).contiguous()
+
+
+def _result(t, as_numpy):
+    return t.cpu().numpy() if as_numpy else t
+
+
 def composite_reg_img(bg, fg, fg_mask, bw_mode=False, device="cuda"):
-    """uint8 HWC images (numpy or tensors) -> uint8 CUDA tensor.  bw_mode is not supported (the reference needs
-    cv2.cvtColor for it)."""
-    if bw_mode:
-        raise NotImplementedError("bw_mode needs a BGR->gray conversion outside the warp path")
+    """uint8 HWC images of one shape -> their alpha composite (compo.py:5-24)."""
+    as_numpy = not any(isinstance(x, torch.Tensor) for x in (bg, fg, fg_mask))
     bg, fg, fg_mask = (_as_cuda(x, device).contiguous() for x in (bg, fg, fg_mask))
     if not (bg.dtype == fg.dtype == fg_mask.dtype == torch.uint8) or not (bg.shape == fg.shape == fg_mask.shape):
         raise ValueError("composite_reg_img needs three uint8 images of one shape")
+    if bw_mode:
+        fg = gray_bgr(fg)
     out = torch.empty_like(bg)
     stream = torch.cuda.current_stream(bg.device).cuda_stream
     with torch.cuda.device(bg.device):
         _lib.check(_lib.load().bevwarp_composite(bg.data_ptr(), fg.data_ptr(), fg_mask.data_ptr(), out.data_ptr(), bg.numel(),
                                                  ctypes.c_void_p(stream)))
-    return out
+    return _result(out, as_numpy)
 
 
 def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_size, y_size, bw_mode=False, device="cuda"):
-    """Returns (compo uint8 CUDA tensor of shape (y_size, x_size, C), H_world2img_cam) like the reference."""
-    bg, fg, fg_mask = (_as_cuda(x, device) for x in (bg, fg, fg_mask))
-    H_img2bev_fix = np.asarray(H_world2bev).dot(H_img2world_fix)
-    bg_bev = warp_perspective(bg, H_img2bev_fix, (x_size, y_size))
+    """Returns (compo, H_world2img_cam) like the reference (compo.py:26-49): compo is (y_size, x_size, C) uint8."""
+    as_numpy = not any(isinstance(x, torch.Tensor) for x in (bg, fg, fg_mask))
+    bg, fg, fg_mask = (_hwc(_as_cuda(x, device)) for x in (bg, fg, fg_mask))
+    if fg.shape != fg_mask.shape or bg.shape[2] != fg.shape[2]:
+        raise ValueError("fg and fg_mask must have one shape, and bg their channel count")
+    if bw_mode:
+        fg = gray_bgr(fg)
+    H_world2bev = np.asarray(H_world2bev, dtype=np.float64)
+    H_img2bev_fix = H_world2bev.dot(np.asarray(H_img2world_fix, dtype=np.float64))
     H_world2img_cam = homo_from_KRt(np.asarray(K), Rt_homo=np.asarray(RT))
-    H_img2bev_cam = np.asarray(H_world2bev).dot(np.linalg.inv(H_world2img_cam))
-    # foreground and mask share one homography: warp them as a batch of two
-    both = torch.stack([fg, fg_mask]) if fg.shape == fg_mask.shape else None
-    if both is not None:
-        w = warp_perspective(both, H_img2bev_cam, (x_size, y_size))
-        fg_bev, mask_bev = w[0], w[1]
-    else:
-        fg_bev = warp_perspective(fg, H_img2bev_cam, (x_size, y_size))
-        mask_bev = warp_perspective(fg_mask, H_img2bev_cam, (x_size, y_size))
-    return composite_reg_img(bg_bev, fg_bev, mask_bev, bw_mode=bw_mode, device=device), H_world2img_cam
+    H_img2bev_cam = H_world2bev.dot(np.linalg.inv(H_world2img_cam))
+    minv = device_inverse(np.stack([H_img2bev_fix, H_img2bev_cam]), bg.device)  # the two inverse maps, one upload
+    C = bg.shape[2]
+    out = torch.empty((int(y_size), int(x_size), C), dtype=torch.uint8, device=bg.device)
+    stream = torch.cuda.current_stream(bg.device).cuda_stream
+    with torch.cuda.device(bg.device):
+        st = _lib.load().bevwarp_warp_composite(
+            bg.data_ptr(), bg.shape[0], bg.shape[1], bg.stride(0), fg.data_ptr(), fg_mask.data_ptr(), fg.shape[0], fg.shape[1], fg.stride(0),
+            fg_mask.stride(0), out.data_ptr(), out.shape[0], out.shape[1], out.stride(0), C, minv.data_ptr(), minv.data_ptr() + 72,
+            ctypes.c_void_p(stream))
+    _lib.check(st)
+    return _result(out, as_numpy), H_world2img_cam

@@ -214,6 +214,21 @@ int bevwarp_composite(const void* bg, const void* fg, const void* mask, void* ou
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
 
+int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_stride, const void* fg, const void* mask, int fg_h, int fg_w,
+                           int64_t fg_row_stride, int64_t mask_row_stride, void* dst, int dst_h, int dst_w, int64_t dst_row_stride, int channels,
+                           const double* M_inv_bg, const double* M_inv_cam, void* stream) {
+    if (!bg || !fg || !mask || !dst || !M_inv_bg || !M_inv_cam) return BEVWARP_ERR_BAD_ARG;
+    if (bg_h <= 0 || bg_w <= 0 || fg_h <= 0 || fg_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
+    if (channels < 1 || channels > 4) return BEVWARP_ERR_UNSUPPORTED;
+    if (bg_row_stride < (int64_t)bg_w * channels || fg_row_stride < (int64_t)fg_w * channels || mask_row_stride < (int64_t)fg_w * channels ||
+        dst_row_stride < (int64_t)dst_w * channels)
+        return BEVWARP_ERR_BAD_ARG;
+    if (bg_w > 32767 || bg_h > 32767 || fg_w > 32767 || fg_h > 32767 || dst_h > 65535) return BEVWARP_ERR_TOO_LARGE;
+    const hipError_t e = bevwarp::launch_warp_composite(bg, bg_h, bg_w, bg_row_stride, fg, mask, fg_h, fg_w, fg_row_stride, mask_row_stride, dst, dst_h, dst_w,
+                                                        dst_row_stride, channels, M_inv_bg, M_inv_cam, block_width(dst_w, dst_h), (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
 int bevwarp_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* M_inv, int m_count,
                       int interp, void* stream) {
     if (!touched || !M_inv || batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;

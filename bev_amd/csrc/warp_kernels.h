@@ -35,6 +35,9 @@ int tile_width(int dtype);   // destination pixels per row segment of one wave: 
 int rows_per_pass();         // rows one pass of a workgroup's waves covers
 int resident_workgroups(int dtype, int channels, int interp);  // workgroups of this format's kernel the device holds at once
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
+hipError_t launch_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_rs, const void* fg, const void* mask, int fg_h, int fg_w, int64_t fg_rs,
+                                 int64_t mask_rs, void* dst, int dst_h, int dst_w, int64_t dst_rs, int channels, const double* m_bg, const double* m_cam,
+                                 int bw0, hipStream_t stream);
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);
 hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, const double* H, int dtype, hipStream_t stream);

@@ -996,6 +996,84 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     }
 }
 
+// ===================================================================================================
+// warp_composite<C>: composite_bev_img in ONE launch (reference bev/tool/compo.py:26-49): every destination pixel samples
+// the background through M_bg and the foreground AND its mask through M_cam (one coordinate pair for both), and blends
+// in registers -- fg * (m / 255) + bg * (1 - m / 255) in float64, round half even, clip -- so none of the three warped
+// images ever exists in memory.  8-bit, bilinear, zero border (what the reference's three warpPerspective calls use).
+// One pixel per lane, lanes along the row; coordinates by the fast chain with the same tie window and exact fallback as
+// warp_rows, taps unguarded when all four lie inside the frame and guarded otherwise.
+// ===================================================================================================
+struct CompositeArgs {
+    const uint8_t *bg, *fg, *mask;
+    uint8_t* dst;
+    const double *m_bg, *m_cam;  // device, inverse matrices
+    int64_t bg_rs, fg_rs, mask_rs, dst_rs;
+    int bg_h, bg_w, fg_h, fg_w, dst_h, dst_w, bw0;
+};
+
+template <int C>
+__device__ __forceinline__ uint32_t sample_u8_linear(const uint8_t* __restrict__ img, int64_t rs, int w, int h, int X, int Y) {
+    const int sx = X >> kInterBits, sy = Y >> kInterBits;
+    const uint32_t fx = (uint32_t)X & 31u, fy = (uint32_t)Y & 31u;
+    constexpr int LB = (2 * C + 3) & ~3;  // bytes of a tap pair, whole dwords
+    if ((uint32_t)sx <= (uint32_t)((int64_t)w * C - LB) / C && (uint32_t)sy < (uint32_t)(h - 1) && (int64_t)w * C >= LB && h >= 2) {
+        uint32_t t[LB / 4], u[LB / 4];
+        const uint8_t* p = img + (int64_t)sy * rs + (int64_t)sx * C;
+        __builtin_memcpy(t, p, LB);
+        __builtin_memcpy(u, p + rs, LB);
+        if constexpr (C == 3) return blend_u8_rgb_window(t[0], t[1], u[0], u[1], fx, fy);
+        if constexpr (C == 4) return blend_u8_packed<C>(t[0], t[1], u[0], u[1], fx, fy);
+        if constexpr (C < 3) return blend_u8_packed<C>(t[0], t[0] >> (8 * C), u[0], u[0] >> (8 * C), fx, fy);
+    }
+    SrcView v;
+    v.frame = img, v.rs = rs, v.w = w, v.h = h, v.bu = 0;
+    for (int k = 0; k < 4; k++) v.bf[k] = 0.f;
+    return sample_global<uint8_t, C, kLinear>(v, X, Y).packed;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void warp_composite(const CompositeArgs a) {
+    using F = Fix<kLinear>;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst_w) return;
+    // the two maps: (X, Y) in 1/32 px of the background frame and of the camera frame
+    int Xs[2], Ys[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double* __restrict__ M = q == 0 ? a.m_bg : a.m_cam;
+        const double xd = (double)x, yd = (double)y;
+        const double W = __builtin_fma(M[6], xd, __builtin_fma(M[7], yd, M[8]));
+        const double r = rcp_newton(W) * kTwo32;
+        const double tx = __builtin_fma(__builtin_fma(M[0], xd, __builtin_fma(M[1], yd, M[2])), r, F::kMagic);
+        const double ty = __builtin_fma(__builtin_fma(M[3], xd, __builtin_fma(M[4], yd, M[5])), r, F::kMagic);
+        const uint32_t hx = (uint32_t)__double2hiint(tx), lx = (uint32_t)__double2loint(tx), hy = (uint32_t)__double2hiint(ty), ly = (uint32_t)__double2loint(ty);
+        const uint32_t we = ((uint32_t)__double2hiint(W) >> 20) & 0x7ffu;
+        // trust the fast chain inside the binade, away from the tie windows, for a sane W; else the reference's chain
+        if ((((hx ^ kHiExp) | (hy ^ kHiExp)) >> 20) == 0 && (lx & F::kTieMask) != 0 && (ly & F::kTieMask) != 0 && we - 824u <= 398u) {
+            Xs[q] = fix_to_int<kLinear>(hx, lx);
+            Ys[q] = fix_to_int<kLinear>(hy, ly);
+        } else {
+            const int bx = (x / a.bw0) * a.bw0;
+            double X0, Y0, W0;
+            row_terms(M, bx, y, X0, Y0, W0);
+            const double x1 = (double)(x - bx);
+            map_pixel_exact<kLinear>(X0 + M[0] * x1, Y0 + M[3] * x1, W0 + M[6] * x1, Xs[q], Ys[q]);
+        }
+    }
+    const uint32_t pb = sample_u8_linear<C>(a.bg, a.bg_rs, a.bg_w, a.bg_h, Xs[0], Ys[0]);
+    const uint32_t pf = sample_u8_linear<C>(a.fg, a.fg_rs, a.fg_w, a.fg_h, Xs[1], Ys[1]);
+    const uint32_t pm = sample_u8_linear<C>(a.mask, a.mask_rs, a.fg_w, a.fg_h, Xs[1], Ys[1]);
+    uint8_t* d = a.dst + (int64_t)y * a.dst_rs + (int64_t)x * C;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        // composite_reg_img, compo.py:16-23, in float64 like numpy: two products, one sum, round half even, clip
+        const double al = (double)((pm >> (8 * k)) & 0xffu) / 255.0;
+        const double v = rint((double)((pf >> (8 * k)) & 0xffu) * al + (double)((pb >> (8 * k)) & 0xffu) * (1.0 - al));
+        d[k] = (uint8_t)(v > 255.0 ? 255.0 : v);
+    }
+}
+
 // Footprint: mark every in-bounds source pixel any tap would read (measurement aid; exact chain).
 template <int INTERP>
 __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch, int src_h, int src_w, int dst_h, int dst_w,
@@ -1093,6 +1171,25 @@ hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, h
         launch_t<uint8_t>(a, channels, interp, grid, stream);
     else
         launch_t<float>(a, channels, interp, grid, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_rs, const void* fg, const void* mask, int fg_h, int fg_w, int64_t fg_rs,
+                                 int64_t mask_rs, void* dst, int dst_h, int dst_w, int64_t dst_rs, int channels, const double* m_bg, const double* m_cam,
+                                 int bw0, hipStream_t stream) {
+    (void)hipGetLastError();
+    CompositeArgs a;
+    a.bg = (const uint8_t*)bg, a.fg = (const uint8_t*)fg, a.mask = (const uint8_t*)mask, a.dst = (uint8_t*)dst;
+    a.m_bg = m_bg, a.m_cam = m_cam;
+    a.bg_rs = bg_rs, a.fg_rs = fg_rs, a.mask_rs = mask_rs, a.dst_rs = dst_rs;
+    a.bg_h = bg_h, a.bg_w = bg_w, a.fg_h = fg_h, a.fg_w = fg_w, a.dst_h = dst_h, a.dst_w = dst_w, a.bw0 = bw0;
+    const dim3 block(256), grid((dst_w + 255) / 256, dst_h);
+    switch (channels) {
+        case 1: hipLaunchKernelGGL(warp_composite<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(warp_composite<2>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(warp_composite<3>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(warp_composite<4>, grid, block, 0, stream, a); break;
+    }
     return hipGetLastError();
 }
 

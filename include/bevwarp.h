@@ -13,6 +13,8 @@
  *                             the reference leaves it to its callers)
  *   bevwarp_composite       composite_reg_img(bg, fg, fg_mask), bev/tool/compo.py:5-24 (the blend after the three warps
  *                             of composite_bev_img, :26-49)
+ *   bevwarp_warp_composite  composite_bev_img(bg, fg, fg_mask, ...), bev/tool/compo.py:26-49: the three warps and the blend
+ *                             in one launch, no warped image in memory
  *   bevwarp_footprint       -- measurement aid (SURVEY.md 8(d) "footprint_px"), no reference twin
  *   bevwarp_project_points  pts_world_bev(pts_src, H), bev/rbox.py:136-151; rbox_world_img, :221-226;
  *                             Calib.gen_center_in_world, bev/calib.py:135-138
@@ -111,6 +113,19 @@ int bevwarp_warp_planar(const void *src, void *dst, int batch, int src_h, int sr
  * channel count, flattened); `out` may alias `bg` or `fg`.
  */
 int bevwarp_composite(const void *bg, const void *fg, const void *mask, void *out, int64_t n, void *stream);
+
+/*
+ * dst = composite_reg_img(warp(bg, M_bg), warp(fg, M_cam), warp(mask, M_cam)) -- bev/tool/compo.py:26-49 -- where the three
+ * warps are bevwarp_warp's BEVWARP_U8 / BEVWARP_LINEAR / zero-border warp to (dst_w, dst_h) and the blend is
+ * bevwarp_composite's, computed per pixel in one launch: the warped images are never written.  Bit-identical to the
+ * three-warp sequence.
+ *   bg (bg_h x bg_w), fg and mask (fg_h x fg_w each), dst: device uint8, `channels` (1..4) interleaved, strides in bytes.
+ *   M_inv_bg, M_inv_cam: device, 9 float64 each, INVERSE maps (dst px -> bg px / camera px).
+ */
+int bevwarp_warp_composite(const void *bg, int bg_h, int bg_w, int64_t bg_row_stride, const void *fg, const void *mask,
+                           int fg_h, int fg_w, int64_t fg_row_stride, int64_t mask_row_stride, void *dst, int dst_h,
+                           int dst_w, int64_t dst_row_stride, int channels, const double *M_inv_bg,
+                           const double *M_inv_cam, void *stream);
 
 /*
  * Marks every in-bounds source pixel that any tap of any destination pixel of the same warp would
