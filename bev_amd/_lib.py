@@ -25,7 +25,7 @@ SYMBOLS = {
                                 _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                 _c.c_void_p, _c.c_void_p]),
     "bevwarp_warp_planar": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                       _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int,
+                                       _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "bevwarp_composite": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     "bevwarp_warp_composite": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int64,

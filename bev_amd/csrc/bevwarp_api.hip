@@ -201,11 +201,11 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
 
 int bevwarp_warp_planar(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,
-                        int64_t dst_row_stride, const double* M_inv, int m_count, int interp, const double* border_value, const double* scale,
-                        const double* bias, void* stream) {
+                        int64_t dst_row_stride, const double* M_inv, int m_count, int dtype, int interp, const double* border_value,
+                        const double* scale, const double* bias, void* stream) {
     const PlanarOut po = {dst_plane_stride, scale, bias};
     return warp_impl(src, dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride,
-                     M_inv, m_count, BEVWARP_U8, interp, border_value, stream, &po);
+                     M_inv, m_count, dtype, interp, border_value, stream, &po);
 }
 
 int bevwarp_composite(const void* bg, const void* fg, const void* mask, void* out, int64_t n, void* stream) {

@@ -19,34 +19,72 @@ struct H9 {
     double h[9];
 };
 
+// 1 / z to the last bit or two of float64: v_rcp_f64 (2^-24) and two Newton steps.  The two IEEE divisions of a point
+// (~62 issue cycles each) were what bound the float32 case; the results stay within 2 ulp of the quotients (the parity
+// bar of this path is rtol 1e-12 against the reference's own vectors).
+__device__ __forceinline__ double rcp_full(double z) {
+    double r = __builtin_amdgcn_rcp(z);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ void project_one(const H9& H, double x, double y, double w, double& ox, double& oy) {
+    const double X = H.h[0] * x + H.h[1] * y + H.h[2] * w;
+    const double Y = H.h[3] * x + H.h[4] * y + H.h[5] * w;
+    const double Z = H.h[6] * x + H.h[7] * y + H.h[8] * w;
+    // (Z == 0 or non-finite: the quotients themselves, so that inf / nan come out as numpy's do)
+    const bool tame = fabs(Z) > 1e-300 && fabs(Z) < 1e300;
+    const double r = rcp_full(Z);
+    ox = tame ? X * r : X / Z;
+    oy = tame ? Y * r : Y / Z;
+}
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef double pf64x2 __attribute__((ext_vector_type(2)));
+// (`out` may be `in`: every lane reads its own points before it writes them, and neither pointer is __restrict__)
+// 16 bytes per lane per step (two float32 points / one float64 point), streamed once: non-temporal both ways.
 template <typename T, int DIM>
-// (`out` may be `in`: every lane reads its own point before it writes it, and neither pointer is __restrict__)
-__global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out, int64_t n, const H9 H) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double x, y, w = 1.0;
-        if constexpr (DIM == 2 && sizeof(T) == 8) {
-            const double2 p = reinterpret_cast<const double2*>(in)[i];
-            x = p.x;
-            y = p.y;
-        } else if constexpr (DIM == 2) {
-            const float2 p = reinterpret_cast<const float2*>(in)[i];
-            x = p.x;
-            y = p.y;
-        } else {
-            x = (double)in[i * 3];
-            y = (double)in[i * 3 + 1];
-            w = (double)in[i * 3 + 2];
+__global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out, int64_t n, const H9 H, int vec16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (DIM == 2 && sizeof(T) == 4) {
+        if (!vec16) {  // buffers that are only 8-byte aligned (a view starting at an odd point): one point per step
+            for (int64_t i = t0; i < n; i += stride) {
+                const float2 p = reinterpret_cast<const float2*>(in)[i];
+                double ax, ay;
+                project_one(H, (double)p.x, (double)p.y, 1.0, ax, ay);
+                reinterpret_cast<float2*>(out)[i] = make_float2((float)ax, (float)ay);
+            }
+            return;
         }
-        const double X = H.h[0] * x + H.h[1] * y + H.h[2] * w;
-        const double Y = H.h[3] * x + H.h[4] * y + H.h[5] * w;
-        const double Z = H.h[6] * x + H.h[7] * y + H.h[8] * w;
-        const double ox = X / Z, oy = Y / Z;
-        if constexpr (DIM == 2 && sizeof(T) == 8) {
-            reinterpret_cast<double2*>(out)[i] = make_double2(ox, oy);
-        } else if constexpr (DIM == 2) {
-            reinterpret_cast<float2*>(out)[i] = make_float2((float)ox, (float)oy);
-        } else {
+        const int64_t pairs = n >> 1;
+        for (int64_t i = t0; i < pairs; i += stride) {
+            const pf32x4 p = __builtin_nontemporal_load(reinterpret_cast<const pf32x4*>(in) + i);
+            double ax, ay, bx, by;
+            project_one(H, (double)p.x, (double)p.y, 1.0, ax, ay);
+            project_one(H, (double)p.z, (double)p.w, 1.0, bx, by);
+            const pf32x4 o = {(float)ax, (float)ay, (float)bx, (float)by};
+            __builtin_nontemporal_store(o, reinterpret_cast<pf32x4*>(out) + i);
+        }
+        if ((n & 1) && t0 == 0) {  // the odd last point
+            double ax, ay;
+            project_one(H, (double)in[2 * (n - 1)], (double)in[2 * (n - 1) + 1], 1.0, ax, ay);
+            out[2 * (n - 1)] = (float)ax;
+            out[2 * (n - 1) + 1] = (float)ay;
+        }
+    } else if constexpr (DIM == 2) {
+        for (int64_t i = t0; i < n; i += stride) {
+            const pf64x2 p = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(in) + i);
+            double ox, oy;
+            project_one(H, p.x, p.y, 1.0, ox, oy);
+            const pf64x2 o = {ox, oy};
+            __builtin_nontemporal_store(o, reinterpret_cast<pf64x2*>(out) + i);
+        }
+    } else {
+        for (int64_t i = t0; i < n; i += stride) {
+            const double x = (double)in[i * 3], y = (double)in[i * 3 + 1], w = (double)in[i * 3 + 2];
+            double ox, oy;
+            project_one(H, x, y, w, ox, oy);
+            const double Z = H.h[6] * x + H.h[7] * y + H.h[8] * w;
             out[i * 3] = (T)ox;
             out[i * 3 + 1] = (T)oy;
             out[i * 3 + 2] = (T)(Z / Z);
@@ -267,19 +305,20 @@ hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, 
     (void)hipGetLastError();
     H9 h;
     for (int i = 0; i < 9; i++) h.h[i] = H[i];
+    const int vec16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     const int block = 256;
     const int64_t want = (n + block - 1) / block;
     const int grid = (int)(want < 256 * 8 ? want : 256 * 8);  // grid-stride above 8 blocks per CU
     if (dtype == 2) {
         if (dim == 2)
-            hipLaunchKernelGGL((project_points_kernel<double, 2>), dim3(grid), dim3(block), 0, stream, (const double*)in, (double*)out, n, h);
+            hipLaunchKernelGGL((project_points_kernel<double, 2>), dim3(grid), dim3(block), 0, stream, (const double*)in, (double*)out, n, h, vec16);
         else
-            hipLaunchKernelGGL((project_points_kernel<double, 3>), dim3(grid), dim3(block), 0, stream, (const double*)in, (double*)out, n, h);
+            hipLaunchKernelGGL((project_points_kernel<double, 3>), dim3(grid), dim3(block), 0, stream, (const double*)in, (double*)out, n, h, vec16);
     } else {
         if (dim == 2)
-            hipLaunchKernelGGL((project_points_kernel<float, 2>), dim3(grid), dim3(block), 0, stream, (const float*)in, (float*)out, n, h);
+            hipLaunchKernelGGL((project_points_kernel<float, 2>), dim3(grid), dim3(block), 0, stream, (const float*)in, (float*)out, n, h, vec16);
         else
-            hipLaunchKernelGGL((project_points_kernel<float, 3>), dim3(grid), dim3(block), 0, stream, (const float*)in, (float*)out, n, h);
+            hipLaunchKernelGGL((project_points_kernel<float, 3>), dim3(grid), dim3(block), 0, stream, (const float*)in, (float*)out, n, h, vec16);
     }
     return hipGetLastError();
 }

@@ -304,7 +304,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // warp_rows<T, C, INTERP, RS4, PLANAR>
 //   RS4     8-bit RGB bilinear only: the source row stride is a multiple of 4 bytes (both tap rows of a pixel then share
 //           one window alignment and one funnel-shift amount)
-//   PLANAR  8-bit sources only: the destination is C float32 planes, dst[c][y][x] = float(pixel) * pscale[c] + pbias[c]
+//   PLANAR  the destination is C float32 planes, dst[c][y][x] = float(pixel) * pscale[c] + pbias[c] (the layout a detector takes)
 // Register budget: 4 waves per SIMD -- what the FAST row loop needs; the rare row classes may spill.
 // ===================================================================================================
 #ifndef BEVWARP_U8LIN_WAVES
@@ -340,7 +340,6 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     constexpr int kM = kAligned ? 2 : 1;         // FAST: both ends inside by this many pixels (the aligned window starts
                                                  // up to 3 bytes early: never before its row)
     constexpr int TRW = 64 * PPL * (sizeof(T) == 1 ? 1 : C);  // dwords of a wave's transposition row
-    static_assert(!PLANAR || sizeof(T) == 1, "planar output is the 8-bit -> float32 egress path");
     static_assert(!RS4 || kAligned, "RS4 only qualifies the aligned-window variant");
     __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves][TRW];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
@@ -728,8 +727,18 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     // -- LDS row -> registers in store order (u8: pixels 4 l .. 4 l + 3 of the segment; float: 16-byte unit u * 64 + l)
     constexpr int kVec = sizeof(T) == 1 ? 64 : TRW / 4;  // 16-byte units in the wave's row segment
     constexpr int NQ = (kVec + 63) / 64;
+    static_assert(NQ * 4 >= PPL * C || sizeof(T) == 1, "the planar float path keeps a lane's PPL pixels in the same registers");
     auto read_back = [&](uint4 (&out)[NQ]) {
         asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
+        if constexpr (PLANAR && sizeof(T) == 4) {  // float planes: the lane's own PPL pixels, channel by channel (pixel 64 j + lane)
+            uint32_t* o = reinterpret_cast<uint32_t*>(&out[0]);
+#pragma unroll
+            for (int j = 0; j < PPL; j++)
+#pragma unroll
+                for (int k = 0; k < C; k++) o[j * C + k] = wtr[(64 * j + lane) * C + k];
+            asm volatile("" ::: "memory");
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NQ; u++) {
             const int q = u * 64 + lane;
@@ -799,6 +808,18 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                 for (int i = 0; i < lane_px; i++)
 #pragma unroll
                     for (int k = 0; k < C; k++) d[i * C + k] = (uint8_t)(p[i] >> (8 * k));
+            }
+        } else if constexpr (PLANAR) {  // float source -> float planes: 64 consecutive floats of a plane row per instruction
+            const float* o = reinterpret_cast<const float*>(&out[0]);
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const int px = kBlk ? xs + lane : xs + 64 * j + lane, py = kBlk ? y + j : y;
+                if (px >= a.dst_w || py > y_last) continue;
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    float* dk = reinterpret_cast<float*>(dframe + k * a.dst_ps + (int64_t)py * a.dst_rs) + px;
+                    __builtin_nontemporal_store(o[j * C + k] * a.pscale[k] + a.pbias[k], dk);
+                }
             }
         } else {
             const int nfl = seg_px * C;  // valid floats of a row of the segment / block
@@ -1103,14 +1124,12 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
 template <typename T, int C, int INTERP>
 void launch_tci(const WarpArgs& a, dim3 grid, hipStream_t stream) {
     constexpr bool kRgb8Lin = sizeof(T) == 1 && C == 3 && INTERP == kLinear;
-    if constexpr (sizeof(T) == 1) {
-        if (a.planar) {
-            if (kRgb8Lin && a.src_rs % 4 == 0)
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true>), grid, dim3(kWG), 0, stream, a);
-            else
-                hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true>), grid, dim3(kWG), 0, stream, a);
-            return;
-        }
+    if (a.planar) {
+        if (kRgb8Lin && a.src_rs % 4 == 0)
+            hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, true>), grid, dim3(kWG), 0, stream, a);
+        else
+            hipLaunchKernelGGL((warp_rows<T, C, INTERP, false, true>), grid, dim3(kWG), 0, stream, a);
+        return;
     }
     if (kRgb8Lin && a.src_rs % 4 == 0)
         hipLaunchKernelGGL((warp_rows<T, C, INTERP, kRgb8Lin, false>), grid, dim3(kWG), 0, stream, a);

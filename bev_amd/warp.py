@@ -160,16 +160,16 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
 
 
 def warp_to_planar(src, M, dsize, scale=1.0 / 255.0, bias=0.0, flags=INTER_LINEAR, border_value=None, out=None, M_inv_device=None):
-    """Warp uint8 frames and write them as normalised float32 channel planes in the same pass (the
-    layout a detector takes, `(B, C, v_size, u_size)`), without materialising the uint8 BEV frame:
+    """Warp uint8 (or float32) frames and write them as normalised float32 channel planes in the same pass (SURVEY.md 8(f2):
+    the layout a detector takes, `(B, C, v_size, u_size)`), without materialising the interleaved BEV frame:
 
         out[b, c] = warp_perspective(src, M, dsize)[b, :, :, c].float() * scale[c] + bias[c]      (float32 mul, then add)
 
-    src (B, H, W, C) / (H, W, C) / (H, W) uint8 CUDA tensor; scale / bias scalars or per-channel sequences (e.g.
+    src (B, H, W, C) / (H, W, C) / (H, W) uint8 or float32 CUDA tensor; scale / bias scalars or per-channel sequences (e.g.
     1 / (255 * std) and -mean / std); other arguments as warp_perspective.  Returns (B, C, h, w), or (C, h, w) for a
     single frame.  Asynchronous on the current stream."""
-    if not isinstance(src, torch.Tensor) or not src.is_cuda or src.dtype != torch.uint8:
-        raise ValueError("warp_to_planar needs a uint8 CUDA (HIP) tensor")
+    if not isinstance(src, torch.Tensor) or not src.is_cuda or src.dtype not in _DTYPES:
+        raise ValueError("warp_to_planar needs a uint8 or float32 CUDA (HIP) tensor")
     interp = int(flags) & 7
     if interp not in (INTER_NEAREST, INTER_LINEAR):
         raise ValueError("unsupported interpolation flag %d" % interp)
@@ -202,8 +202,8 @@ def warp_to_planar(src, M, dsize, scale=1.0 / 255.0, bias=0.0, flags=INTER_LINEA
     stream = torch.cuda.current_stream(s4.device).cuda_stream
     with torch.cuda.device(s4.device):
         st = _lib.load().bevwarp_warp_planar(
-            s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C, s4.stride(0), s4.stride(1),
-            d4.stride(0) * 4, d4.stride(1) * 4, d4.stride(2) * 4, M_inv_device.data_ptr(), n_m, interp,
+            s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C, s4.stride(0) * s4.element_size(), s4.stride(1) * s4.element_size(),
+            d4.stride(0) * 4, d4.stride(1) * 4, d4.stride(2) * 4, M_inv_device.data_ptr(), n_m, _DTYPES[s4.dtype], interp,
             None if bv is None else bv.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
             bi.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(stream))
     _lib.check(st)

@@ -8,7 +8,7 @@
  *   bevwarp_warp            cv2.warpPerspective(img, H_bev_img, (u_size, v_size))
  *                             vis_homo.py:89, vis_homo.py:91, bev/tool/compo.py:38,46,47
  *   bevwarp_invert_homography  the cv::invert(M) step inside that call (M is the forward src->dst map)
- *   bevwarp_warp_planar     the same warp of 8-bit frames, written as normalised float32 channel planes in the same
+ *   bevwarp_warp_planar     the same warp (8-bit or float32 frames), written as normalised float32 channel planes in the same
  *                             pass (the layout step between vis_homo.py:89 and a detector's input;
  *                             the reference leaves it to its callers)
  *   bevwarp_composite       composite_reg_img(bg, fg, fg_mask), bev/tool/compo.py:5-24 (the blend after the three warps
@@ -93,19 +93,19 @@ int bevwarp_warp(const void *src, void *dst, int batch, int src_h, int src_w, in
                  void *stream);
 
 /*
- * 8-bit source, float32 PLANAR destination, one pass:
- *   dst[b][c][y][x] = (float)warp_u8(src[b])[y][x][c] * scale[c] + bias[c]      (float32 multiply, then add)
- * where warp_u8 is exactly what bevwarp_warp computes for BEVWARP_U8 (same interpolation, rounding and border).
+ * float32 PLANAR destination, one pass:
+ *   dst[b][c][y][x] = (float)warp(src[b])[y][x][c] * scale[c] + bias[c]      (float32 multiply, then add)
+ * where warp is exactly what bevwarp_warp computes for `dtype` (BEVWARP_U8 | BEVWARP_F32: same interpolation, rounding
+ * and border).
  *   dst             device float32; dst_plane_stride bytes between channel planes, dst_row_stride between rows,
  *                   dst_frame_stride between frames (all multiples of 4; multiples of 16 enable the wide stores).
  *   scale, bias     HOST, `channels` doubles each (converted to float32); NULL = 1 and 0.
- * Returns BEVWARP_ERR_UNSUPPORTED for destinations fewer than 16 rows high whose evaluation block width
- * (1024 / dst_h) is not a multiple of 4 and narrower than the image.
  */
 int bevwarp_warp_planar(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,
-                        int64_t dst_row_stride, const double *M_inv, int m_count, int interp, const double *border_value /*HOST*/,
-                        const double *scale /*HOST*/, const double *bias /*HOST*/, void *stream);
+                        int64_t dst_row_stride, const double *M_inv, int m_count, int dtype, int interp,
+                        const double *border_value /*HOST*/, const double *scale /*HOST*/, const double *bias /*HOST*/,
+                        void *stream);
 
 /*
  * out[i] = uint8(min(round_half_even(fg[i] * (mask[i] / 255) + bg[i] * (1 - mask[i] / 255)), 255)) for i in [0, n), computed in

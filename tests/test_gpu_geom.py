@@ -249,3 +249,32 @@ def test_composite_reg_img_matches_numpy_expression():
         exp = (fgv.astype(float) * mf + bg.astype(float) * (1 - mf)).round()
         exp[exp > 255] = 255
         np.testing.assert_array_equal(composite_reg_img(bg[..., None], fgv[..., None], mv[..., None])[..., 0], exp.astype(np.uint8))
+
+
+def test_frame_pipeline_matches_resident_path():
+    """SURVEY.md 8(f2) ingest: pinned host ring -> H2D -> warp -> D2H on three streams; the results are the resident path's."""
+    from bev_amd import warp as W
+    from bev_amd.pipeline import FramePipeline
+    from tests import workloads as wl
+    sw, sh, dw, dh = 640, 360, 256, 192
+    M = wl.synth_brno_H(sw, sh, dw, dh)
+    frames = [wl.frame(60 + i, sh, sw, np.uint8) for i in range(7)]
+    exp = [co.warp_perspective(f, M, (dw, dh), 1) for f in frames]
+    pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=3)
+    got = [r.copy() for r in pipe.run(frames)]  # (results are views of a pinned ring)
+    assert len(got) == len(frames)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+    # zero-copy ingest (the decoder writes into the pinned slot), results left on the device, planar egress
+    pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=2, planar=True, scale=[1 / 255.0, 0.5, 2.0], bias=[0.0, -1.0, 3.5], download=False)
+    for i, f in enumerate(frames[:4]):
+        pipe.next_input()[...] = f
+        pipe.commit()
+        r = pipe.result()
+        ref = W.warp_to_planar(torch.from_numpy(f).cuda(), M, (dw, dh), scale=[1 / 255.0, 0.5, 2.0], bias=[0.0, -1.0, 3.5])
+        assert r.is_cuda and torch.equal(r, ref)
+    # float32 frames
+    f32 = [wl.frame(70 + i, sh, sw, np.float32) for i in range(3)]
+    pipe = FramePipeline((sh, sw), 3, M, (dw, dh), dtype=torch.float32)
+    for g, f in zip(pipe.run(f32), f32):
+        np.testing.assert_array_equal(g, co.warp_perspective(f, M, (dw, dh), 1))

@@ -236,3 +236,18 @@ def test_staged_tiles_planar_output(W):
         u8 = co.warp_perspective(frames[i], Ms[i], (dw, dh), 1)
         exp = np.stack([u8[:, :, k].astype(np.float32) * np.float32(scale[k]) + np.float32(bias[k]) for k in range(3)])
         np.testing.assert_array_equal(got[i], exp)
+
+
+@pytest.mark.parametrize("kind,c,dw,dh", [("keystone", 3, 512, 80), ("brno", 3, 300, 37), ("brno", 1, 256, 32), ("keystone", 4, 130, 16), ("brno", 2, 70, 5)])
+def test_planar_output_of_float_sources(W, kind, c, dw, dh):
+    """bevwarp_warp_planar for float32 frames: planes of float(warp) * scale + bias, every tile path (interior rows, interior
+    blocks, edge blocks), ragged tiles."""
+    sw, sh = 640, 360
+    M = (wl.keystone_H if kind == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh)
+    src = wl.frame(31, sh, sw, np.float32, c)
+    scale, bias = np.linspace(0.5, 2.0, c), np.linspace(-1.0, 1.0, c)
+    for interp in (0, 1):
+        got = W.warp_to_planar(torch.from_numpy(src).cuda(), M, (dw, dh), scale=scale, bias=bias, flags=interp).cpu().numpy()
+        ref = co.warp_perspective(src, M, (dw, dh), interp).reshape(dh, dw, c)
+        exp = ref.transpose(2, 0, 1) * scale.astype(np.float32)[:, None, None] + bias.astype(np.float32)[:, None, None]
+        np.testing.assert_array_equal(got, exp.astype(np.float32))
