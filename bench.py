@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- BEV Mpix/s of the batched homography warp (BASELINE.json metric) on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|u8] [--interp linear|nearest]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|u8] [--interp linear|nearest] [--config 1|3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config 3]
 
-A "step" is one launch of the hot path over one batch of synthetic frames already resident in HBM:
-BASELINE.json configs[1] = 32 x (1920x1080x3 -> 1024x1024x3) bilinear warp, "keystone" homography with a
-per-frame +-2 px jitter.  The headline line is the float32-pixel variant (north_star:
-"float bilinear"); the 8-bit variants of the same workload (the pixel type of the reference's video
-frames) are timed in the same run and reported under "variants" (N = 1 only).  Frames shard by rank
-with no data-path collective (weak scaling: every rank warps its own 32 frames); torch.distributed is
-used for the barrier and the max-over-ranks time only.  Several distinct buffer sets (> 1 GB in total)
-are rotated so that a step never finds its frames in the 256 MB Infinity Cache left by the previous one.
+A "step" is one launch of the hot path over one batch of synthetic frames already resident in HBM.  The headline is
+BASELINE.json configs[1] = 32 x (1920x1080x3 -> 1024x1024x3) bilinear warp per GPU, "keystone" homography with a per-frame
++-2 px jitter, float32 pixels (north_star: "float bilinear"); `--config 3` switches every rank to its
+shard of configs[3] (32 x (3840x2160 -> 2048x2048), 256 frames over 8 GPUs) with the same JSON schema.  Frames shard by
+rank with no data-path collective (weak scaling); torch.distributed carries the barrier and the max-over-ranks time only.
+Several distinct buffer sets (> 1 GB in total) are rotated so that a step never finds its frames in the 256 MB Infinity
+Cache left by the previous one.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / mean launch
-duration from HIP events on the launch stream; algorithmic bytes = every destination byte once +
-every distinct in-bounds source pixel touched by any tap once (exact footprint, counted on the GPU by
-bevwarp_footprint).  `roofline.traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes
-(profiles/pmc_traffic.json; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE).  `cpu_baseline` times the CPU oracle
-(plain-C restatement of the reference's cv2.warpPerspective path) on this box's host cores on a bounded
-sample of the same workload and doubles as the checker of the GPU output.
+ONE JSON line (rank 0).  At N = 1 it also carries, measured in the same run:
+  variants   the other pixel types of configs[1] -- uint8 bilinear (the reference's own pixel type, vis_homo.py:86-89) and
+             nearest, uint8 -> float32 planes -- and the rotated "brno" footprint for uint8 and float32
+  configs    configs[0] (one 720p -> 512^2 uint8 frame: GPU resident / PCIe-inclusive, CPU oracle 1 thread and all cores,
+             cv2 when this box happens to have it), configs[2] (1e7 points, f32 / f64), configs[3] (the per-GPU shard,
+             uint8 and float32), configs[4] (1080p -> 1024^2 uint8 warp + the 512 x 512 tracker launch, eager and replayed
+             from a hipGraph), and the PCIe-inclusive frame pipeline
+`roofline.achieved` = algorithmic bytes per launch / mean launch duration from HIP events on the launch stream; algorithmic
+bytes = every destination byte once + every distinct in-bounds source pixel touched by any tap once (exact footprint,
+counted on the GPU by bevwarp_footprint).  `roofline.traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
+passes (profiles/pmc_traffic.json; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) -- null unless that file was produced from the
+kernel source this run was built from.  `cpu_baseline` times the CPU oracle (plain-C restatement of the reference's
+cv2.warpPerspective path) on this box's host cores on a bounded sample of the headline workload and doubles as the checker
+of the GPU output.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,7 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec; ~5.0-6.0 TB/s streaming copy on this box)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec; ~5.0-6.3 TB/s streaming copy)
+KERNEL_SOURCES = ("bev_amd/csrc/warp_kernels.hip", "bev_amd/csrc/warp_kernels.h", "bev_amd/csrc/bevwarp_api.hip")
 
 
 def parse():
@@ -45,29 +53,74 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--dtype", choices=["u8", "f32"], default="f32")
     p.add_argument("--interp", choices=["linear", "nearest"], default="linear")
+    p.add_argument("--config", type=int, choices=[1, 3], default=1, help="BASELINE.json configs[] index of the per-GPU workload")
     p.add_argument("--batch", type=int, default=32)
-    p.add_argument("--src", type=int, nargs=2, default=[1920, 1080], metavar=("W", "H"))
-    p.add_argument("--dst", type=int, nargs=2, default=[1024, 1024], metavar=("W", "H"))
+    p.add_argument("--src", type=int, nargs=2, default=None, metavar=("W", "H"))
+    p.add_argument("--dst", type=int, nargs=2, default=None, metavar=("W", "H"))
     p.add_argument("--homography", choices=["keystone", "brno"], default="keystone")
     p.add_argument("--sets", type=int, default=0, help="distinct buffer sets to rotate (0 = enough for > 1 GB)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-variants", action="store_true", help="skip the extra 8-bit measurements (N = 1)")
+    p.add_argument("--no-variants", action="store_true", help="skip the extra measurements of configs[1] (N = 1)")
+    p.add_argument("--no-configs", action="store_true", help="skip the configs block (N = 1)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
-    return p.parse_args()
+    a = p.parse_args()
+    shape = {1: ([1920, 1080], [1024, 1024]), 3: ([3840, 2160], [2048, 2048])}[a.config]
+    a.src = a.src or shape[0]
+    a.dst = a.dst or shape[1]
+    return a
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 16))  # a one-GPU box owns a 16-core share of the host
+
+
+def cv2_leg(frames_np, Ms, dsize, interp, oracle_out):
+    """Opportunistic: when this box already has OpenCV, time cv2.warpPerspective on the same sample and
+    report its largest pixel difference from the oracle.  Never a requirement, never installed."""
+    try:
+        import cv2  # noqa: F401
+    except Exception:
+        return None
+    if not hasattr(cv2, "warpPerspective"):
+        return None
+    flag = cv2.INTER_LINEAR if interp == 1 else cv2.INTER_NEAREST
+    mpix = dsize[0] * dsize[1] / 1e6
+    out = {"version": getattr(cv2, "__version__", "?")}
+    diff = 0.0
+    for f, M, o in zip(frames_np, Ms, oracle_out):
+        diff = max(diff, float(np.abs(cv2.warpPerspective(f, M, dsize, flags=flag).astype(np.float64) - o.astype(np.float64)).max()))
+    out["max_abs_diff_vs_oracle"] = diff
+    for label, nt in (("single_thread_value", 1), ("value", 0)):
+        cv2.setNumThreads(nt)
+        t0, n = time.perf_counter(), 0
+        while n < len(frames_np) or time.perf_counter() - t0 < 1.0:
+            cv2.warpPerspective(frames_np[n % len(frames_np)], Ms[n % len(frames_np)], dsize, flags=flag)
+            n += 1
+        out[label] = round(n * mpix / (time.perf_counter() - t0), 2)
+    out["unit"] = "Mpix/s"
+    return out
 
 
 def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
     """Time the oracle (kind "port") on a bounded sample; also use it as the checker of the GPU output."""
     from oracle import cpu_oracle as co
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # a one-GPU box owns a 16-core share of the host
+    cores = host_cores()
     dw, dh = dsize
     mpix = dw * dh / 1e6
     nf = len(frames_np)
-    n, t_all, ok = 0, 0.0, True
+    n, t_all, ok, oracle_out = 0, 0.0, True, []
     t_end = time.perf_counter() + 0.6 * budget_s
     while n < nf or time.perf_counter() < t_end:  # cycle over the sample frames until the budget is spent
         t0 = time.perf_counter()
@@ -75,6 +128,7 @@ def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
         t_all += time.perf_counter() - t0
         if n < nf:
             ok = ok and np.array_equal(exp, gpu_out[n])
+            oracle_out.append(exp)
         n += 1
     m, t_one = 0, 0.0
     t_end = time.perf_counter() + 0.4 * budget_s
@@ -83,35 +137,56 @@ def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
         co.warp_perspective(frames_np[m % nf], Ms[m % nf], dsize, interp, nthreads=1)
         t_one += time.perf_counter() - t0
         m += 1
-    return {
+    res = {
         "value": round(n * mpix / t_all, 2), "unit": "Mpix/s", "cores": cores, "kind": "port",
         "sample": "%d warps of the step's first %d frames by oracle/liboracle.so with %d OpenMP threads (%.1f s); "
                   "single thread: %d warps (%.1f s)" % (n, nf, cores, t_all, m, t_one),
         "single_thread_value": round(m * mpix / t_one, 2),
         "gpu_output_matches_oracle": bool(ok),
     }
+    cv = cv2_leg(frames_np, Ms, dsize, interp, oracle_out)
+    res["cv2_opportunistic"] = cv if cv is not None else "cv2 not importable on this box"
+    return res
 
 
 def load_traffic(dtype, interp, args):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None when the
-    workload is not the one that was profiled (configs[1] at its default shape)."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None when the workload is not the one
+    that was profiled (configs[1] at its default shape) or the kernel source has changed since."""
     if (args.batch, tuple(args.src), tuple(args.dst), args.homography) != (32, (1920, 1080), (1024, 1024), "keystone"):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get("%s_%s" % (dtype, interp), {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
     except (OSError, ValueError):
         return None
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None
+    return d.get("%s_%s" % (dtype, interp), {}).get("hbm_bytes_per_launch")
+
+
+def event_times(fn, n, warm):
+    """Per-call durations (s) of fn() from HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return np.array([a.elapsed_time(b) for a, b in ev]) * 1e-3
 
 
 class Workload:
-    """One dtype / interpolation variant of configs[1] resident on one GPU."""
+    """One dtype / interpolation variant of a batched warp resident on one GPU."""
 
-    def __init__(self, args, dtype, interp_name, rank, dev, planar=False):
+    def __init__(self, args, dtype, interp_name, rank, dev, planar=False, homography=None, device_frames=False):
         from bev_amd import warp
-        self.planar = planar  # uint8 in, normalised float32 channel planes out (bevwarp_warp_planar, SURVEY.md 8(f2))
         from tests import workloads as wl
+        self.planar = planar  # float32 channel planes out (bevwarp_warp_planar, SURVEY.md 8(f2))
         self.warp, self.dtype, self.interp_name, self.args = warp, dtype, interp_name, args
+        self.homography = homography or args.homography
         self.B = B = args.batch
         self.sw, self.sh = sw, sh = args.src
         self.dw, self.dh = dw, dh = args.dst
@@ -119,23 +194,28 @@ class Workload:
         tdtype, ndtype, esz = (torch.uint8, np.uint8, 1) if dtype == "u8" else (torch.float32, np.float32, 4)
         self.esz = esz
         self.interp = warp.INTER_LINEAR if interp_name == "linear" else warp.INTER_NEAREST
-        base = (wl.keystone_H if args.homography == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh)
+        base = (wl.keystone_H if self.homography == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh)
         gidx = [rank * B + i for i in range(B)]  # global frame indices of this rank
         self.Ms = np.stack([wl.jitter_H(base, g) for g in gidx])
         out_esz = 4 if planar else esz
         self.set_bytes = B * (sh * sw * esz + dh * dw * out_esz) * C
         self.nsets = args.sets or max(2, int(np.ceil(1.1e9 / self.set_bytes)))
-        self.frames_np = [wl.frame(g, sh, sw, ndtype) for g in gidx[:min(B, 8)]]
+        self.frames_np = [] if device_frames else [wl.frame(g, sh, sw, ndtype) for g in gidx[:min(B, 8)]]
         self.srcs, self.dsts = [], []
         for s in range(self.nsets):
-            t = torch.empty((B, sh, sw, C), dtype=tdtype, device=dev)
-            for i in range(B):
-                if s == 0 and i < len(self.frames_np):
-                    t[i] = torch.from_numpy(self.frames_np[i]).to(dev)
-                elif s == 0:
-                    t[i] = torch.from_numpy(wl.frame(gidx[i], sh, sw, ndtype)).to(dev)
-                else:  # other sets: same statistics, different bytes (cheap on-device generation)
-                    t[i] = self.srcs[0][(i + s) % B].flip(0) if s % 2 else self.srcs[0][(i + s) % B].flip(1)
+            if device_frames:  # seeded on the device: same statistics as wl.frame, no host generation (not compared with the oracle)
+                gen = torch.Generator(device=dev).manual_seed(1234 + 1000 * rank + s)
+                t = (torch.randint(0, 256, (B, sh, sw, C), dtype=torch.uint8, device=dev, generator=gen) if dtype == "u8"
+                     else torch.rand((B, sh, sw, C), dtype=torch.float32, device=dev, generator=gen))
+            else:
+                t = torch.empty((B, sh, sw, C), dtype=tdtype, device=dev)
+                for i in range(B):
+                    if s == 0 and i < len(self.frames_np):
+                        t[i] = torch.from_numpy(self.frames_np[i]).to(dev)
+                    elif s == 0:
+                        t[i] = t[i % len(self.frames_np)].flip(0) if (i // len(self.frames_np)) % 2 else t[i % len(self.frames_np)].flip(1)
+                    else:  # other sets: same statistics, different bytes (cheap on-device generation)
+                        t[i] = self.srcs[0][(i + s) % B].flip(0) if s % 2 else self.srcs[0][(i + s) % B].flip(1)
             self.srcs.append(t)
             self.dsts.append(torch.empty((B, C, dh, dw), dtype=torch.float32, device=dev) if planar else torch.empty((B, dh, dw, C), dtype=tdtype, device=dev))
         self.minv = warp.device_inverse(self.Ms, dev)
@@ -170,11 +250,179 @@ class Workload:
         kernel_s = float(launch_ms.mean()) / 1e3
         achieved = self.algo_bytes / kernel_s / 1e9
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if self.planar else load_traffic(self.dtype, self.interp_name, self.args),
-                "kernel": "warp_gather<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None if (self.planar or self.homography != "keystone") else load_traffic(self.dtype, self.interp_name, self.args),
+                "kernel": "warp_rows<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
                 "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
                 "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
                 "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
+
+
+def variant_line(w, steps, warmup, barrier, label=None):
+    el, lm = w.run(steps, warmup, barrier)
+    return {"dtype": label or w.dtype, "interp": w.interp_name, "homography": w.homography,
+            "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4), "roofline": w.roofline(lm)}
+
+
+# ---- the other configs of BASELINE.json, bounded (N = 1) -------------------------------------------------------------------
+def config0(dev):
+    """configs[0]: ONE 1280x720 uint8 frame -> 512x512 BEV, bilinear, synth-brno homography (the canonical CPU row)."""
+    from bev_amd import warp
+    from bev_amd.pipeline import FramePipeline
+    from oracle import cpu_oracle as co
+    from tests import workloads as wl
+    sw, sh, dw, dh = 1280, 720, 512, 512
+    M = wl.synth_brno_H(sw, sh, dw, dh)
+    img = wl.frame(0, sh, sw, np.uint8)
+    mpix = dw * dh / 1e6
+    src, out = torch.from_numpy(img).to(dev), torch.empty((dh, dw, 3), dtype=torch.uint8, device=dev)
+    minv = warp.device_inverse(M, dev)
+    t = event_times(lambda: warp.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv), 200, 20)
+    exp = co.warp_perspective(img, M, (dw, dh), 1, nthreads=1)
+    res = {"workload": "one 1280x720x3 uint8 frame -> 512x512 BEV, bilinear, synth-brno homography",
+           "gpu_resident": {"us_median": round(float(np.median(t)) * 1e6, 2), "us_min": round(float(t.min()) * 1e6, 2),
+                            "Mpix_per_s": round(mpix / float(np.median(t)), 1), "matches_oracle": bool(np.array_equal(out.cpu().numpy(), exp))}}
+    hs = []
+    for _ in range(25):
+        t0 = time.perf_counter()
+        warp.warpPerspective(img, M, (dw, dh))
+        hs.append(time.perf_counter() - t0)
+    res["gpu_pcie_inclusive_serial"] = {"ms_median": round(float(np.median(hs[5:])) * 1e3, 4), "Mpix_per_s": round(mpix / float(np.median(hs[5:])), 1),
+                                        "what": "bev.warp.warpPerspective: pageable numpy frame up, BEV frame down, one call at a time"}
+    cores = host_cores()
+    for label, nt in (("cpu_oracle_1_thread", 1), ("cpu_oracle_all_cores", cores)):
+        ts = []
+        for _ in range(55):
+            t0 = time.perf_counter()
+            co.warp_perspective(img, M, (dw, dh), 1, nthreads=nt)
+            ts.append(time.perf_counter() - t0)
+        res[label] = {"ms_median": round(float(np.median(ts[5:])) * 1e3, 4), "Mpix_per_s": round(mpix / float(np.median(ts[5:])), 2), "threads": nt, "runs": 50}
+    cv = cv2_leg([img], [M], (dw, dh), 1, [exp])
+    res["cv2_opportunistic"] = cv if cv is not None else "cv2 not importable on this box"
+    return res
+
+
+def config2(dev):
+    """configs[2]: 1e7 (u, v) points through a 3x3 H (bev.rbox.pts_world_bev), float32 and float64."""
+    from bev_amd.points import project_points
+    H = np.array([[0.02, -0.001, -3.0], [0.0004, 0.05, -20.0], [1e-5, 0.0009, 0.4]])
+    N = 10_000_000
+    res = {}
+    for dt, tdt, esz in (("f32", torch.float32, 4), ("f64", torch.float64, 8)):
+        nbuf = max(2, int(np.ceil(600e6 / (N * 2 * esz * 2))))  # rotate past the 256 MB Infinity Cache
+        gen = torch.Generator(device=dev).manual_seed(7)
+        ins = [(torch.rand((N, 2), dtype=torch.float64, device=dev, generator=gen) * torch.tensor([1920.0, 1080.0], device=dev, dtype=torch.float64)).to(tdt)
+               for _ in range(nbuf)]
+        outs = [torch.empty_like(x) for x in ins]
+        k = [0]
+
+        def step():
+            project_points(ins[k[0] % nbuf], H, out=outs[k[0] % nbuf])
+            k[0] += 1
+
+        t = event_times(step, 60, 6)
+        nbytes = N * 2 * esz * 2
+        res[dt] = {"us_mean": round(float(t.mean()) * 1e6, 2), "us_min": round(float(t.min()) * 1e6, 2), "Gpts_per_s": round(N / float(t.mean()) / 1e9, 2),
+                   "roofline": {"bound": "hbm", "achieved": round(nbytes / float(t.mean()) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(nbytes / float(t.mean()) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                "kernel": "project_points_kernel<%s,2>" % ("float" if esz == 4 else "double"), "algorithmic_bytes_per_launch": nbytes}}
+        del ins, outs
+        torch.cuda.empty_cache()
+    res["workload"] = "1e7 (u, v) points through a 3x3 H, dehomogenised; bytes = N x 2 coordinates x (in + out)"
+    return res
+
+
+def config3(args, dev, barrier):
+    """configs[3]: the per-GPU shard, 32 x (3840x2160 -> 2048x2048), uint8 and float32 bilinear (device-generated frames)."""
+    a3 = argparse.Namespace(**vars(args))
+    a3.src, a3.dst, a3.batch, a3.sets, a3.homography = [3840, 2160], [2048, 2048], 32, 2, "keystone"
+    res = {"workload": "32 x (3840x2160x3 -> 2048x2048x3) bilinear, keystone: one GPU's shard of the 256-frame, 8-GPU config"}
+    for dt in ("u8", "f32"):
+        w = Workload(a3, dt, "linear", 0, dev, device_frames=True)
+        res[dt] = variant_line(w, 12, 3, barrier)
+        del w
+        torch.cuda.empty_cache()
+    return res
+
+
+def config4(dev):
+    """configs[4]: one camera frame's step -- 1080p -> 1024^2 uint8 bilinear warp + the tracker launch on 512 x 512 boxes."""
+    from bev_amd import warp
+    from bev_amd.graph import GraphedStep
+    from bev_amd.iou import rbox_iou
+    from bev_amd.tracker_geom import tracker_geometry_step
+    from tests import workloads as wl
+    rng = np.random.default_rng(11)
+    M = wl.synth_brno_H(1920, 1080, 1024, 1024)
+    frames = [torch.from_numpy(wl.frame(i, 1080, 1920, np.uint8)).to(dev) for i in range(4)]
+    outs = [torch.empty((1024, 1024, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+    minv = warp.device_inverse(M, dev)
+    H_world_bev = np.array([[0.0, 0.0625, -10.0], [-0.0625, 0.0, 40.0], [0, 0, 1.0]])
+    H_img_world = np.linalg.inv(np.array([[0.02, -0.001, -3.0], [0.0004, 0.05, -20.0], [1e-5, 0.0009, 0.4]]))
+    dets = torch.from_numpy(np.column_stack([rng.uniform(0, 1024, (512, 2)), rng.uniform(25, 35, 512), rng.uniform(56, 96, 512), rng.uniform(-np.pi, np.pi, 512)])).to(dev)
+    trks = torch.from_numpy(np.column_stack([rng.uniform(-10, 54, 512), rng.uniform(-24, 40, 512), rng.uniform(1.6, 2.2, 512), rng.uniform(3.5, 6, 512),
+                                             rng.uniform(-np.pi, np.pi, 512)])).to(dev)
+    buf = tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world)
+    k = [0]
+
+    def step():
+        i = k[0] % 4
+        warp.warp_perspective(frames[i], None, (1024, 1024), out=outs[i], M_inv_device=minv)
+        tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf)
+        k[0] += 1
+
+    te = event_times(step, 200, 20)
+    tt = event_times(lambda: tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf), 200, 20)
+    ti = event_times(lambda: rbox_iou(dets, trks), 200, 20)
+    res = {"workload": "one 1920x1080 uint8 frame -> 1024x1024 BEV (bilinear, synth-brno) + bevwarp_tracker_step on 512 detections x 512 tracks (float64)",
+           "step_eager_us": round(float(te.mean()) * 1e6, 1), "step_eager_us_min": round(float(te.min()) * 1e6, 1),
+           "tracker_launch_us": round(float(tt.mean()) * 1e6, 1), "rbox_iou_512x512_us": round(float(ti.mean()) * 1e6, 1)}
+    try:
+        g = GraphedStep(step)
+        tg = event_times(g.replay, 200, 20)
+        res["step_graph_us"] = round(float(tg.mean()) * 1e6, 1)
+        res["step_graph_us_min"] = round(float(tg.min()) * 1e6, 1)
+    except Exception as e:  # graph capture is an optimisation of the harness, not of the path
+        res["step_graph_error"] = "%s: %s" % (type(e).__name__, e)
+    return res
+
+
+def pipeline_config(dev):
+    """PCIe-inclusive frames/s of 1080p -> 1024^2 uint8: one call at a time against the three-stream pipeline (never `value`)."""
+    from bev_amd import warp
+    from bev_amd.pipeline import FramePipeline
+    from tests import workloads as wl
+    M = wl.keystone_H(1920, 1080, 1024, 1024)
+    img = wl.frame(0, 1080, 1920, np.uint8)
+    for _ in range(3):
+        warp.warpPerspective(img, M, (1024, 1024))
+    t0 = time.perf_counter()
+    for _ in range(20):
+        warp.warpPerspective(img, M, (1024, 1024))
+    serial = (time.perf_counter() - t0) / 20
+    pipe = FramePipeline((1080, 1920), 3, M, (1024, 1024), depth=3)
+    n = 200
+    for i in range(3):  # fill the slots once: afterwards the "decoder" finds its frame already in pinned memory (zero-copy ingest)
+        pipe.next_input()[...] = img
+        pipe.commit()
+    for _ in range(3):
+        pipe.result()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n):
+        pipe.next_input()
+        pipe.commit()
+        if pipe.ready() >= 3:
+            pipe.result()
+            done += 1
+    while pipe.ready():
+        pipe.result()
+        done += 1
+    piped = (time.perf_counter() - t0) / n
+    return {"workload": "1920x1080x3 uint8 host frames -> 1024x1024 BEV frames on the host (PCIe both ways)", "serial_ms_per_frame": round(serial * 1e3, 4),
+            "pipelined_ms_per_frame": round(piped * 1e3, 4), "speedup": round(serial / piped, 2), "pipelined_frames_per_s": round(1 / piped, 1),
+            "what": "bev.warp.warpPerspective per frame vs bev_amd.pipeline.FramePipeline (pinned ring, H2D / warp / D2H on three streams, depth 3)"}
 
 
 def main():
@@ -195,7 +443,8 @@ def main():
     dev = torch.device("cuda", dev_index)
     shard.init(backend=backend, device=dev)  # no-op for one process; RCCL only carries the barrier / max below
 
-    main_wl = Workload(args, args.dtype, args.interp, rank, dev)
+    big = args.config == 3
+    main_wl = Workload(args, args.dtype, args.interp, rank, dev, device_frames=big and args.no_cpu_baseline)
     elapsed, launch_ms = main_wl.run(args.steps, args.warmup, shard.barrier)
     elapsed = shard.max_over_ranks(elapsed)
 
@@ -203,17 +452,18 @@ def main():
         B, dw, dh, sw, sh = main_wl.B, main_wl.dw, main_wl.dh, main_wl.sw, main_wl.sh
         mpix_total = world * B * dw * dh * args.steps / 1e6
         result = {
-            "metric": "BEV Mpix/s, 1080p->1024^2 warp; achieved HBM GB/s vs peak",
+            "metric": "BEV Mpix/s, %s warp; achieved HBM GB/s vs peak" % ("1080p->1024^2" if not big else "2160p->2048^2"),
             "value": round(mpix_total / elapsed, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=%d %dx%dx3 -> %dx%dx3 %s warp per GPU, %s pixels, %s homography (+-2 px per-frame jitter)"
-                                   % (B, sw, sh, dw, dh, args.interp, "float32" if args.dtype == "f32" else "uint8", args.homography),
+            "config": {"workload": "configs[%d]: batch=%d %dx%dx3 -> %dx%dx3 %s warp per GPU, %s pixels, %s homography (+-2 px per-frame jitter)"
+                                   % (args.config, B, sw, sh, dw, dh, args.interp, "float32" if args.dtype == "f32" else "uint8", args.homography),
                        "frames_per_gpu": B, "sharding": "frames split by rank, no collectives",
-                       "buffer_sets_rotated": main_wl.nsets, "resident_bytes_per_gpu": main_wl.nsets * main_wl.set_bytes},
+                       "buffer_sets_rotated": main_wl.nsets, "resident_bytes_per_gpu": main_wl.nsets * main_wl.set_bytes,
+                       "kernel_source_sha": kernel_source_sha()},
             "roofline": main_wl.roofline(launch_ms),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and main_wl.frames_np:
             gpu_out = main_wl.dsts[0][:len(main_wl.frames_np)].cpu().numpy()  # set 0 holds the seeded frames
             result["cpu_baseline"] = cpu_baseline(main_wl.frames_np, main_wl.Ms, (dw, dh), main_wl.interp, gpu_out, args.cpu_seconds)
     del main_wl
@@ -221,17 +471,28 @@ def main():
 
     if world == 1 and not args.no_variants:
         variants = []
-        for dt, ip, planar in (("u8", "linear", False), ("u8", "nearest", False), ("f32", "linear", False), ("u8", "linear", True)):
-            if (dt, ip) == (args.dtype, args.interp) and not planar:
+        n = max(20, args.steps // 2)
+        for dt, ip, planar, hom in (("u8", "linear", False, "keystone"), ("u8", "nearest", False, "keystone"), ("f32", "linear", False, "keystone"),
+                                    ("u8", "linear", True, "keystone"), ("u8", "linear", False, "brno"), ("f32", "linear", False, "brno"),
+                                    ("u8", "nearest", False, "brno")):
+            if (dt, ip, hom) == (args.dtype, args.interp, args.homography) and not planar:
                 continue
-            w = Workload(args, dt, ip, rank, dev, planar=planar)
-            el, lm = w.run(max(20, args.steps // 2), max(5, args.warmup // 2), shard.barrier)
-            n = max(20, args.steps // 2)
-            variants.append({"dtype": dt if not planar else "u8 -> f32 planar", "interp": ip, "value": round(w.B * w.dw * w.dh * n / 1e6 / el, 1), "unit": "Mpix/s",
-                             "ms_per_step": round(el / n * 1e3, 4), "roofline": w.roofline(lm)})
+            w = Workload(args, dt, ip, rank, dev, planar=planar, homography=hom, device_frames=True)
+            variants.append(variant_line(w, n, max(5, args.warmup // 2), shard.barrier, label=dt if not planar else "u8 -> f32 planar"))
             del w
             torch.cuda.empty_cache()
         result["variants"] = variants
+
+    if world == 1 and not args.no_configs:
+        cfg = {}
+        for name, fn in (("configs[0]", lambda: config0(dev)), ("configs[2]", lambda: config2(dev)), ("configs[3]", lambda: config3(args, dev, shard.barrier)),
+                         ("configs[4]", lambda: config4(dev)), ("pcie_pipeline", lambda: pipeline_config(dev))):
+            try:
+                cfg[name] = fn()
+            except Exception as e:  # a failing side measurement must not lose the headline line
+                cfg[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        result["configs"] = cfg
 
     if rank == 0:
         print(json.dumps(result), flush=True)

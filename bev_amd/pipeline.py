@@ -14,11 +14,40 @@ normalised float32 channel planes (the layout a detector takes), in the same pas
 for bit: the same kernel runs on the same bytes.
 """
 import collections
+import ctypes
 
 import numpy as np
 import torch
 
+from . import _lib
 from . import warp as _warp
+
+_hip = None
+
+
+def _hip_rt():
+    """The HIP runtime torch already loaded, bound through ctypes: a frame's eight asynchronous calls (two copies, the
+    launch, the events that chain the three streams) cost ~2 us each this way; through torch's stream context managers they
+    cost more host time than the transfers take, and the pipeline would be bound by the Python loop."""
+    global _hip
+    if _hip is None:
+        h = ctypes.CDLL("libamdhip64.so")
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        for name, args in (("hipMemcpyAsync", [vp, vp, sz, ctypes.c_int, vp]), ("hipEventCreateWithFlags", [ctypes.POINTER(vp), ctypes.c_uint]),
+                           ("hipEventRecord", [vp, vp]), ("hipStreamWaitEvent", [vp, vp, ctypes.c_uint]), ("hipEventSynchronize", [vp]),
+                           ("hipEventDestroy", [vp])):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = ctypes.c_int, args
+        _hip = h
+    return _hip
+
+
+def _ok(err):
+    if err != 0:
+        raise _lib.BevWarpError("HIP runtime call failed with error %d" % err)
+
+
+_H2D, _D2H = 1, 2  # hipMemcpyHostToDevice / hipMemcpyDeviceToHost
 
 
 class FramePipeline:
@@ -40,12 +69,62 @@ class FramePipeline:
         self.d_out = [torch.empty(out_shape, dtype=out_dtype, device=self.device) for _ in range(depth)]
         self.h_out = [torch.empty(out_shape, dtype=out_dtype, pin_memory=True) for _ in range(depth)] if download else None
         self.minv = _warp.device_inverse(M, self.device, inverse_given=bool(int(flags) & _warp.WARP_INVERSE_MAP))
-        self.s_up, self.s_run, self.s_down = (torch.cuda.Stream(self.device) for _ in range(3))
-        self.ev_up = [torch.cuda.Event() for _ in range(depth)]
-        self.ev_run = [torch.cuda.Event() for _ in range(depth)]
-        self.ev_down = [torch.cuda.Event() for _ in range(depth)]
+        self._streams = [torch.cuda.Stream(self.device) for _ in range(3)]  # (kept alive: their raw handles are used below)
+        self.s_up, self.s_run, self.s_down = (ctypes.c_void_p(st.cuda_stream) for st in self._streams)
+        hip = _hip_rt()
+
+        def events():
+            evs = []
+            for _ in range(depth):
+                e = ctypes.c_void_p()
+                _ok(hip.hipEventCreateWithFlags(ctypes.byref(e), 2))  # hipEventDisableTiming
+                evs.append(e)
+            return evs
+
+        self.ev_up, self.ev_run, self.ev_down = events(), events(), events()
+        # one prepared launch per slot: the C ABI call with its arguments bound (validated once, here, through the Python layer)
+        for slot in range(depth):
+            self._launch_py(slot, torch.cuda.current_stream(self.device))
+        torch.cuda.synchronize(self.device)
+        interp = int(flags) & 7
+        esz = self.d_in[0].element_size()
+        lib = _lib.load()
+        self._launch = []
+        for slot in range(depth):
+            s, d = self.d_in[slot], self.d_out[slot]
+            if planar:
+                sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (self.C,)))
+                bi = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, dtype=np.float64), (self.C,)))
+                self._keep = getattr(self, "_keep", []) + [sc, bi]
+                args = (s.data_ptr(), d.data_ptr(), 1, self.H, self.W, self.dh, self.dw, self.C, s.numel() * esz, s.stride(0) * esz, d.numel() * 4,
+                        d.stride(0) * 4, d.stride(1) * 4, self.minv.data_ptr(), 1, _warp._DTYPES[s.dtype], interp, None,
+                        sc.ctypes.data_as(ctypes.c_void_p), bi.ctypes.data_as(ctypes.c_void_p), self.s_run)
+                self._launch.append((lib.bevwarp_warp_planar, args))
+            else:
+                args = (s.data_ptr(), d.data_ptr(), 1, self.H, self.W, self.dh, self.dw, self.C, s.numel() * esz, s.stride(0) * esz, d.numel() * esz,
+                        d.stride(0) * esz, self.minv.data_ptr(), 1, _warp._DTYPES[s.dtype], interp, None, self.s_run)
+                self._launch.append((lib.bevwarp_warp, args))
+        self._in_bytes = self.h_in[0].numel() * esz
+        self._out_bytes = self.d_out[0].numel() * self.d_out[0].element_size()
         self.n_in = 0
         self.pending = collections.deque()  # slots whose results have not been handed out yet
+
+    def __del__(self):
+        try:
+            hip = _hip_rt()
+            for e in self.ev_up + self.ev_run + self.ev_down:
+                hip.hipEventDestroy(e)
+        except Exception:
+            pass
+
+    def _launch_py(self, slot, stream):
+        """The same launch through bev_amd.warp (argument validation; used once per slot at construction)."""
+        with torch.cuda.stream(stream):
+            if self.planar:
+                _warp.warp_to_planar(self.d_in[slot], None, (self.dw, self.dh), scale=self.scale, bias=self.bias, flags=self.flags, out=self.d_out[slot],
+                                     M_inv_device=self.minv)
+            else:
+                _warp.warp_perspective(self.d_in[slot], None, (self.dw, self.dh), flags=self.flags, out=self.d_out[slot], M_inv_device=self.minv)
 
     # -- input side
     def next_input(self):
@@ -53,28 +132,23 @@ class FramePipeline:
         Blocks only if that slot's previous frame has not left the device yet."""
         slot = self.n_in % self.depth
         if self.n_in >= self.depth:
-            (self.ev_down if self.download else self.ev_run)[slot].synchronize()  # its previous occupant is through
+            _ok(_hip_rt().hipEventSynchronize((self.ev_down if self.download else self.ev_run)[slot]))  # its previous occupant is through
         return self.h_in[slot].numpy()
 
     def commit(self):
+        hip = _hip_rt()
         slot = self.n_in % self.depth
         self.n_in += 1
-        with torch.cuda.stream(self.s_up):
-            self.d_in[slot].copy_(self.h_in[slot], non_blocking=True)
-            self.ev_up[slot].record(self.s_up)
-        with torch.cuda.stream(self.s_run):
-            self.s_run.wait_event(self.ev_up[slot])
-            if self.planar:
-                _warp.warp_to_planar(self.d_in[slot], None, (self.dw, self.dh), scale=self.scale, bias=self.bias, flags=self.flags, out=self.d_out[slot],
-                                     M_inv_device=self.minv)
-            else:
-                _warp.warp_perspective(self.d_in[slot], None, (self.dw, self.dh), flags=self.flags, out=self.d_out[slot], M_inv_device=self.minv)
-            self.ev_run[slot].record(self.s_run)
+        _ok(hip.hipMemcpyAsync(self.d_in[slot].data_ptr(), self.h_in[slot].data_ptr(), self._in_bytes, _H2D, self.s_up))
+        _ok(hip.hipEventRecord(self.ev_up[slot], self.s_up))
+        _ok(hip.hipStreamWaitEvent(self.s_run, self.ev_up[slot], 0))
+        fn, args = self._launch[slot]
+        _lib.check(fn(*args))
+        _ok(hip.hipEventRecord(self.ev_run[slot], self.s_run))
         if self.download:
-            with torch.cuda.stream(self.s_down):
-                self.s_down.wait_event(self.ev_run[slot])
-                self.h_out[slot].copy_(self.d_out[slot], non_blocking=True)
-                self.ev_down[slot].record(self.s_down)
+            _ok(hip.hipStreamWaitEvent(self.s_down, self.ev_run[slot], 0))
+            _ok(hip.hipMemcpyAsync(self.h_out[slot].data_ptr(), self.d_out[slot].data_ptr(), self._out_bytes, _D2H, self.s_down))
+            _ok(hip.hipEventRecord(self.ev_down[slot], self.s_down))
         self.pending.append(slot)
 
     def submit(self, frame):
@@ -92,9 +166,9 @@ class FramePipeline:
         committed) or the device tensor.  Blocks until that frame is through."""
         slot = self.pending.popleft()
         if self.download:
-            self.ev_down[slot].synchronize()
+            _ok(_hip_rt().hipEventSynchronize(self.ev_down[slot]))
             return self.h_out[slot].numpy()
-        self.ev_run[slot].synchronize()
+        _ok(_hip_rt().hipEventSynchronize(self.ev_run[slot]))
         return self.d_out[slot]
 
     def run(self, frames):

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the committed rocprofv3 summaries (tools/prof.sh output copied to profiles/).
 HBM bytes per launch = FETCH_SIZE (KiB) x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB) x 1024."""
+import hashlib
 import json
 import os
 import re
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out = {}
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+# the kernel source the profiled library was built from: bench.py reports `traffic` only while it still matches
+h = hashlib.sha256()
+for rel in ("bev_amd/csrc/warp_kernels.hip", "bev_amd/csrc/warp_kernels.h", "bev_amd/csrc/bevwarp_api.hip"):
+    with open(os.path.join(root, rel), "rb") as f:
+        h.update(f.read())
+out = {"kernel_source_sha": h.hexdigest()[:16]}
 for tag in ("u8_linear", "f32_linear", "u8_nearest"):
     path = os.path.join(root, "profiles", "%s_%s_rocprofv3_summary.txt" % (rnd, tag))
     txt = open(path).read()
