@@ -255,3 +255,34 @@ def test_every_tile_shape_matches_oracle(W, dtype, interp):
         Mo = wl.synth_brno_H(320, 200, 301, 41)
         got = W.warp_perspective(torch.from_numpy(src).cuda(), Mo, (301, 41), flags=interp).cpu().numpy()
         check(got, co.warp_perspective(src, Mo, (301, 41), interp))
+
+
+def test_config4_full_per_gpu_shard_properties(W):
+    """configs[3] at the size one GPU holds: 32 x (3840x2160 -> 2048x2048) uint8, per-frame homographies.  Oracle on three
+    frames; size-independent properties on all of them (a frame's result does not depend on its batch position, the identity
+    homography reproduces the crop, frames of one launch do not leak into each other)."""
+    sw, sh, dw, dh, B = 3840, 2160, 2048, 2048, 32
+    base = wl.keystone_H(sw, sh, dw, dh)
+    Ms = np.stack([wl.jitter_H(base, i) for i in range(B)])
+    uniq = [torch.from_numpy(wl.frame(80 + i, sh, sw, np.uint8)).cuda() for i in range(4)]
+    frames = torch.empty((B, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    for i in range(B):
+        frames[i] = uniq[i % 4] if i < 4 else uniq[i % 4].flip(i % 2)
+    out = W.warp_perspective(frames, Ms, (dw, dh))
+    for i in (0, 3, 31):
+        exp = co.warp_perspective(frames[i].cpu().numpy(), Ms[i], (dw, dh), nthreads=8)
+        assert np.array_equal(out[i].cpu().numpy(), exp), "frame %d" % i
+    # batch-position invariance: frame 5 and its homography moved to slot 29 (and the reverse) give the same pixels
+    perm = list(range(B))
+    perm[5], perm[29] = 29, 5
+    out_p = W.warp_perspective(frames[perm], Ms[perm], (dw, dh))
+    assert torch.equal(out_p[29], out[5]) and torch.equal(out_p[5], out[29]) and torch.equal(out_p[11], out[11])
+    # a shard is the same as its frames one by one (no leakage between frames of a launch)
+    for i in (7, 30):
+        assert torch.equal(W.warp_perspective(frames[i], Ms[i], (dw, dh)), out[i])
+    # identity homography: the top-left crop of every frame, nearest and bilinear
+    for flags in (0, 1):
+        crop = W.warp_perspective(frames, np.eye(3), (dw, dh), flags=flags)
+        assert torch.equal(crop, frames[:, :dh, :dw])
+    del frames, out, out_p, crop
+    torch.cuda.empty_cache()

@@ -47,6 +47,14 @@ def patch(src, spec):
         rep("    uint32_t* wtr = &s_tr[wave][0];\n", "    uint32_t* wtr = &s_tr[wave][0];\n    uint32_t tr_reg[4] = {0, 0, 0, 0};\n")
         rep("            wtr[64 * j + lane] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);", "            tr_reg[j & 3] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);")
         rep("    auto read_back = [&](uint4 (&out)[NQ]) {\n", "    auto read_back = [&](uint4 (&out)[NQ]) {\n        if (sizeof(T) == 1) { out[0] = make_uint4(tr_reg[0], tr_reg[1], tr_reg[2], tr_reg[3]); return; }\n")
+    elif spec == "ntload":  # float taps through non-temporal loads (streaming probe: nt loads + nt stores is the box's best mix)
+        rep("                __builtin_memcpy(&t0[j], b0 + off, LOADB);\n                if (INTERP == kLinear) __builtin_memcpy(&t1[j], b1 + off, LOADB);\n",
+            "                for (int k = 0; k < LOADB / 4; k++) {\n"
+            "                    t0[j].w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(b0 + off) + k);\n"
+            "                    if (INTERP == kLinear) t1[j].w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(b1 + off) + k);\n"
+            "                }\n")
+    elif spec == "noedge":  # EDGE passes cost what OUT passes cost (upper bound of what a cheaper guarded path can gain)
+        rep("            else if (cls == kEdge)\n                edge_s(S1, S2);\n", "            else if (cls == kEdge)\n                fill_s();\n")
     elif spec == "notie":
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
     else:
