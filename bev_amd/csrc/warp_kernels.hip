@@ -54,6 +54,13 @@ struct RowSeg {
 struct BlkSeg {
     static constexpr bool blk = true;
 };
+// where the exact chain is instantiated: inside a row loop (its matrix loads must stay in the rare branch) or after one
+struct InLoop {
+    static constexpr bool value = true;
+};
+struct InTail {
+    static constexpr bool value = false;
+};
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t magic, uint32_t d) {
     // magic = floor(2^32 / d) + 1, exact while n * d < 2^32 (host guarantees); magic == 0 -> plain division
@@ -308,7 +315,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Register budget: 4 waves per SIMD -- what the FAST row loop needs; the rare row classes may spill.
 // ===================================================================================================
 #ifndef BEVWARP_U8LIN_WAVES
-#define BEVWARP_U8LIN_WAVES 3
+#define BEVWARP_U8LIN_WAVES 4
 #endif
 // Diagnostic build only (-DBEVWARP_CLOCK, tools/clock.py): wave 0 of every workgroup adds the shader-clock ticks
 // (s_memtime) and the 100 MHz reference ticks (s_memrealtime) it lived for; their ratio is the clock the chip held.
@@ -425,10 +432,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
     // the reference's chain for pixel j of this lane (rare: tie windows, SLOW rows); the matrix is re-read here so that the
     // row loop does not carry it in registers
-    auto exact_px = [&](auto own, int xs, int y, int j, int& Xe, int& Ye) __attribute__((always_inline)) {  // xs: the block's first pixel
+    auto exact_px = [&](auto own, auto in_loop, int xs, int y, int j, int& Xe, int& Ye) __attribute__((always_inline)) {  // xs: the block's first pixel
         constexpr bool kBlk = decltype(own)::blk;
         const double* Mp = M;
-        asm volatile("" : "+s"(Mp));  // (keeps the loads below inside this rare branch)
+        if constexpr (decltype(in_loop)::value) asm volatile("" : "+s"(Mp));  // (keeps the loads below inside this rare branch of a row loop)
         double Me[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Me[i] = Mp[i];
@@ -500,14 +507,14 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         for (int j = 0; j < PPL; j++) {
             if ((lx[j] & F::kTieMask) == 0 || (ly[j] & F::kTieMask) == 0) {
                 int Xe, Ye;
-                exact_px(own, xs, y, j, Xe, Ye);
+                exact_px(own, InLoop{}, xs, y, j, Xe, Ye);
                 int_to_fix<INTERP>(Xe, hx[j], lx[j]);
                 int_to_fix<INTERP>(Ye, hy[j], ly[j]);
             }
         }
     };
     // (block ownership: y = the block's first row)
-    auto coords_s = [&](int strip, int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) -> int {
+    auto coords_s = [&](int strip, int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) -> int {
         constexpr bool kBlk = true;
         set_strip(strip);
         uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], w_first, w_last;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     };
 
     // -- issue the row's tap loads (rows that are not FAST load the dummy window: the row loop keeps one shape)
-    auto issue_s = [&](int cls, const uint32_t (&S0)[PPL], Bytes<WINB> (&t0)[PPL], Bytes<WINB> (&t1)[PPL]) {
+    auto issue_s = [&](int cls, const uint32_t (&S0)[PPL], Bytes<WINB> (&t0)[PPL], Bytes<WINB> (&t1)[PPL]) __attribute__((always_inline)) {
         const bool f = cls == kFast;
         const uint8_t* b0 = f ? (kAligned ? frame_al : frame) : dummy;
         const uint32_t rs_eff = f ? rs32 : 0u;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     };
     // FAST row of the gather path: taps from the registers the row's loads filled
     auto finish_s = [&](const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
-                        const Bytes<WINB> (&t1)[PPL]) {
+                        const Bytes<WINB> (&t1)[PPL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             const uint32_t fx = S1[j] >> 27, fy = S2[j] >> 27;  // (bilinear only)
@@ -662,11 +669,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         for (int j = 0; j < PPL; j++) put_px(j, v);
     };
     // SLOW row: exact chain and guarded taps for each of the lane's pixels (same ownership, same store order)
-    auto slow_s = [&](int xs, int y) __attribute__((always_inline)) {
+    auto slow_s = [&](auto own, auto in_loop, int xs, int y) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             int Xe, Ye;
-            exact_px(BlkSeg{}, xs, y, j, Xe, Ye);
+            exact_px(own, in_loop, xs, y, j, Xe, Ye);
             put_px(j, sample_global<T, C, INTERP>(view, Xe, Ye));
         }
     };
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     constexpr int kVec = sizeof(T) == 1 ? 64 : TRW / 4;  // 16-byte units in the wave's row segment
     constexpr int NQ = (kVec + 63) / 64;
     static_assert(NQ * 4 >= PPL * C || sizeof(T) == 1, "the planar float path keeps a lane's PPL pixels in the same registers");
-    auto read_back = [&](uint4 (&out)[NQ]) {
+    auto read_back = [&](uint4 (&out)[NQ]) __attribute__((always_inline)) {
         asm volatile("" ::: "memory");  // compiler fence: one wave's LDS operations execute in program order
         if constexpr (PLANAR && sizeof(T) == 4) {  // float planes: the lane's own PPL pixels, channel by channel (pixel 64 j + lane)
             uint32_t* o = reinterpret_cast<uint32_t*>(&out[0]);
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
     };
     auto finish_any = [&](int cls, int xs, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
-                          const Bytes<WINB> (&t1)[PPL]) {
+                          const Bytes<WINB> (&t1)[PPL]) __attribute__((always_inline)) {
         if (__builtin_expect(cls == kFast, 1)) {
             finish_s(S0, S1, S2, t0, t1);
         } else {
@@ -756,14 +763,14 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             else if (cls == kEdge)
                 edge_s(S1, S2);
             else
-                slow_s(xs, y);
+                slow_s(BlkSeg{}, InLoop{}, xs, y);
         }
     };
 
     // -- stores.  The destination is written once and never read back by this kernel: non-temporal stores keep it from
     // displacing source lines in L2 / MALL.  Lanes of a ragged last tile (and every lane when the destination's layout
     // does not admit the wide stores) fall back to element stores.
-    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {  // xs = first pixel of the segment / block
+    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {  // xs = first pixel of the segment / block
         constexpr bool kBlk = decltype(own)::blk;
         const int seg_px = min(kBlk ? 64 : TW, a.dst_w - xs);  // valid pixels of a row of the segment / block
         // 8-bit: a lane stores 4 consecutive pixels: of the wave's row (pixels 4 l ..), or of row l / 16 of its block (pixels 4 (l % 16) ..)
@@ -923,7 +930,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         return;
     }
     // -- interior tiles: no row classes; software-pipelined (the next pass's loads in flight, the pass after that getting its
-    // coordinates, while the previous one is stored and the current one blended)
+    // coordinates, while the previous one is stored and the current one blended).
+    // Pixels in a tie window are not fixed where they are found: the pass is blended from its fast coordinates (a unit off
+    // at worst -- still inside the frame, the tile test keeps a pixel of margin for exactly this), a flag is shifted into a
+    // scalar mask, and flagged passes (rare) are redone whole by the exact chain after the loop.  With the exact chain out
+    // of the loop its state fits 128 VGPRs: four waves per SIMD instead of three (-12 %: DESIGN.md section 6.2).
     auto interior = [&](auto own) __attribute__((always_inline)) {
         constexpr bool kBlk = decltype(own)::blk;
         Pass p_cur, p_nxt;  // p_cur: the pass whose pixels sit in the LDS row; p_nxt: the pass whose coordinates are in the C state
@@ -934,23 +945,30 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         if (!kBlk) UX = __builtin_fma(RX, (double)p_nxt.y, CX), UY = __builtin_fma(RY, (double)p_nxt.y, CY), UW = __builtin_fma(RW, (double)p_nxt.y, CW);
         auto coords_f = [&](const Pass& p, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
             uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
-            uint32_t tie;
             if constexpr (kBlk) {
                 set_strip(p.strip);
-                tie = chain(own, p.y, hx, lx, hy, ly, wf_, wl_);
+                chain(own, p.y, hx, lx, hy, ly, wf_, wl_);
             } else {
-                tie = chain_u(own, UX, UY, UW, hx, lx, hy, ly, wf_, wl_);
+                chain_u(own, UX, UY, UW, hx, lx, hy, ly, wf_, wl_);
                 UX += SX;
                 UY += SY;
                 UW += SW;
             }
-            if (tie == 0) fix_ties(own, xb, p.y, hx, lx, hy, ly);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
                 S0[j] = __umul24(hy[j], rs32) + (__umul24(hx[j], (uint32_t)PBs) + kOff);
                 S1[j] = lx[j];
                 S2[j] = ly[j];
             }
+        };
+        uint64_t tie_passes = 0;  // bit k: the pass blended k passes before the last one has a pixel in a tie window
+        int n_blended = 0;        // (at most 64 passes per wave and tile: the host keeps tiles <= 64 rows)
+        auto note_ties = [&](const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
+            uint32_t tie = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) tie = min(tie, min(S1[j] & F::kTieMask, S2[j] & F::kTieMask));
+            tie_passes = (tie_passes << 1) | (uint64_t)(__ballot(tie == 0) != 0ull);
+            n_blended++;
         };
         bool more;
         auto step = [&](uint32_t (&C0)[PPL], uint32_t (&C1)[PPL], uint32_t (&C2)[PPL], uint32_t (&N0)[PPL], uint32_t (&N1)[PPL], uint32_t (&N2)[PPL])
@@ -963,6 +981,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             if (more) coords_f(p_nxt, N0, N1, N2);
             store_s(own, pass_x(p_st), p_st.y, out);  // behind the loads: vmcnt retires in issue order
             finish_s(C0, C1, C2, u0, u1);
+            note_ties(C1, C2);
         };
         coords_f(p_nxt, A0, A1, A2);
         issue_s(kFast, A0, u0, u1);
@@ -970,6 +989,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         more = next_pass(own, p_nxt);
         if (more) coords_f(p_nxt, B0, B1, B2);
         finish_s(A0, A1, A2, u0, u1);
+        note_ties(A1, A2);
         while (more) {  // (two steps per trip: the states swap roles instead of being copied)
             step(B0, B1, B2, A0, A1, A2);
             if (!more) break;
@@ -977,6 +997,19 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
         read_back(out);
         store_s(own, pass_x(p_cur), p_cur.y, out);
+        if (__builtin_expect(tie_passes != 0, 0)) {  // redo the flagged passes: every pixel by the exact chain and the generic sampler
+            Pass p;
+            first_pass(own, p);
+            int k = n_blended - 1;
+            do {
+                if ((tie_passes >> k) & 1ull) {
+                    slow_s(own, InTail{}, pass_x(p), p.y);
+                    read_back(out);
+                    store_s(own, pass_x(p), p.y, out);
+                }
+                k--;
+            } while (next_pass(own, p));
+        }
     };
     if (tile_in) {
         if (tile_slanted)

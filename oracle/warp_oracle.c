@@ -16,9 +16,13 @@
  * lives in un-vendored, un-pinned third-party packages (opencv-python; d3d)
  * that are absent from /root/reference and from this image, and the reference
  * holds no test, fixture or golden image for them.  The warp below restates
- * the published algorithm of OpenCV 4.x `imgproc/src/imgwarp.cpp`
+ * the published algorithm of OpenCV 3.x-4.x `modules/imgproc/src/imgwarp.cpp`
  * (cv::warpPerspective -> cv::invert 3x3 -> WarpPerspectiveInvoker -> cv::remap
- * with CV_16SC2 + CV_16UC1 fixed-point maps), scalar code path, and is pinned
+ * with CV_16SC2 + CV_16UC1 fixed-point maps; INTER_BITS = 5,
+ * INTER_REMAP_COEF_BITS = 15), the classic scalar code path -- NOT the IPP or
+ * OpenCL dispatches and not the OpenCV 5 rewrite, which may differ in last
+ * bits.  "Bit-exact" anywhere in this repository means: equal to THIS
+ * algorithm, not to whatever cv2 build a user has installed.  It is pinned
  * by the analytic known-answer tests in tests/test_oracle_warp.py and by an
  * independent numpy twin (oracle/warp_numpy.py).  pts_world_bev IS pinned:
  * tests/golden/reference_vectors.json holds outputs of the reference itself.

@@ -3,7 +3,7 @@
 for spec in "$@"; do
   IFS='|' read -r label envs args <<< "$spec"
   out=gpurun_out/ab_$label.json
-  env $envs python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-variants $args > $out 2> gpurun_out/ab_$label.err || { echo "$label FAILED"; tail -3 gpurun_out/ab_$label.err; continue; }
+  env $envs python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-variants --no-configs $args > $out 2> gpurun_out/ab_$label.err || { echo "$label FAILED"; tail -3 gpurun_out/ab_$label.err; continue; }
   python - <<PY
 import json
 d=json.load(open("$out")); r=d["roofline"]

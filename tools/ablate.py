@@ -9,8 +9,10 @@ Each spec patches a COPY of warp_kernels.hip:
     noblend   finish_s xors the taps instead of blending
     stsmall   stores go to a few KB per frame (no HBM write traffic)
     ldsmall   taps come from the first 64 KB of the frame (cache hits)
-    notrans   8-bit: pixels stay in registers (no LDS transposition; wrong layout in memory, same work otherwise)
     notie     no tie-window test in the coordinate chain
+    ntload    float taps through non-temporal loads
+    noedge    EDGE blocks cost what OUT blocks cost
+    ownrow / ownblk   interior tiles forced to row-segment / block ownership (the slant rule's A/B)
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
 import subprocess
@@ -27,8 +29,8 @@ def patch(src, spec):
         assert old in src, (spec, old[:60])
         src = src.replace(old, new, 1)
     if spec == "nostore":
-        rep("    auto store_s = [&](int y, const uint4 (&out)[NQ]) {\n",
-            "    auto store_s = [&](int y, const uint4 (&out)[NQ]) {\n"
+        rep("    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {  // xs = first pixel of the segment / block\n",
+            "    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {\n"
             "        asm volatile(\"\" ::\"v\"(out[0].x), \"v\"(out[0].y), \"v\"(out[0].z), \"v\"(out[0].w));\n        if (y != 12345678) return;\n")
     elif spec == "noload":
         rep("#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n",
@@ -36,17 +38,13 @@ def patch(src, spec):
             "t1[j].w[k] = S0[j] ^ (0x9e3779b9u * (k + 1));\n        if (cls != 12345678) return;\n"
             "#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n")
     elif spec == "noblend":
-        rep("            blend_put(j, w0, w1, fx, fy);\n        }\n    };\n",
-            "            wtr[64 * j + lane] = (w0[0] ^ w1[0] ^ w0[NEED - 1] ^ w1[NEED - 1]) + fx + fy;\n        }\n    };\n")
+        rep("            blend_put(j, w0, w1, fx, fy);\n",
+            "            wtr[64 * j + lane] = (w0[0] ^ w1[0] ^ w0[NEED - 1] ^ w1[NEED - 1]) + fx + fy;\n")
     elif spec == "stsmall":
-        rep("            uint8_t* d = dframe + (int64_t)y * a.dst_rs + (int64_t)(x0 + lane * PPL) * C;\n",
-            "            uint8_t* d = dframe + (int64_t)(y & 7) * a.dst_rs + (int64_t)((x0 & 255) + lane * PPL) * C;\n")
+        rep("            uint8_t* d = dframe + (int64_t)(y + st_row) * a.dst_rs + (int64_t)st_x * C;\n",
+            "            uint8_t* d = dframe + (int64_t)((y + st_row) & 7) * a.dst_rs + (int64_t)(st_x & 255) * C;\n")
     elif spec == "ldsmall":
         rep("            const uint32_t off = S0[j];\n", "            const uint32_t off = S0[j] & 0xffffu;\n")
-    elif spec == "notrans":  # 8-bit only: pixels stay in registers (lane-interleaved order goes to memory: wrong layout, same work minus LDS)
-        rep("    uint32_t* wtr = &s_tr[wave][0];\n", "    uint32_t* wtr = &s_tr[wave][0];\n    uint32_t tr_reg[4] = {0, 0, 0, 0};\n")
-        rep("            wtr[64 * j + lane] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);", "            tr_reg[j & 3] = px;\n        } else {\n            const float* f0 = reinterpret_cast<const float*>(&w0[0]);")
-        rep("    auto read_back = [&](uint4 (&out)[NQ]) {\n", "    auto read_back = [&](uint4 (&out)[NQ]) {\n        if (sizeof(T) == 1) { out[0] = make_uint4(tr_reg[0], tr_reg[1], tr_reg[2], tr_reg[3]); return; }\n")
     elif spec == "ntload":  # float taps through non-temporal loads (streaming probe: nt loads + nt stores is the box's best mix)
         rep("                __builtin_memcpy(&t0[j], b0 + off, LOADB);\n                if (INTERP == kLinear) __builtin_memcpy(&t1[j], b1 + off, LOADB);\n",
             "                for (int k = 0; k < LOADB / 4; k++) {\n"
@@ -57,6 +55,10 @@ def patch(src, spec):
         rep("            else if (cls == kEdge)\n                edge_s(S1, S2);\n", "            else if (cls == kEdge)\n                fill_s();\n")
     elif spec == "notie":
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
+    elif spec == "ownrow":  # interior tiles: row segments whatever the slant
+        rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = false;\n")
+    elif spec == "ownblk":  # interior tiles: blocks whatever the slant
+        rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = true;\n")
     else:
         raise SystemExit("unknown spec " + spec)
     return src
