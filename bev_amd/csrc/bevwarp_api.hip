@@ -147,6 +147,9 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
         if (per_row_of_tiles * ((dst_h + 23) / 24) >= 2 * (int64_t)resident_workgroups(dtype, channels, interp)) a.tile_h = 24;
     }
 #ifdef BEVWARP_TILE_H  // experiments only
+#if BEVWARP_TILE_H > 64
+#error "tiles of at most 64 rows: a wave keeps one flag bit per pass"
+#endif
     a.tile_h = BEVWARP_TILE_H;
 #endif
     a.tiles_x = (dst_w + tw - 1) / tw;
@@ -156,6 +159,9 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     const int64_t chunk = (a.total_tiles + 7) / 8;
     if (chunk * 8 > 0x7fffffffLL || dst_w > (1 << 20) || dst_h > (1 << 20)) return BEVWARP_ERR_TOO_LARGE;
     a.chunk = (int)chunk;
+    // Frames of one launch usually share a footprint: left alone, all eight XCDs would be in the same part of a frame --
+    // outside tiles (store-bound) or interior tiles (latency-bound) -- at the same time.  XCD k starts k/8 of a frame in.
+    a.stagger = chunk >= a.tiles_per_frame ? a.tiles_per_frame / 8 : 0;
     // division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
     auto magic = [](uint64_t n_max, uint32_t d) -> uint32_t {
         return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u;

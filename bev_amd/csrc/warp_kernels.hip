@@ -363,7 +363,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     } clock_stamp;
 #endif
     // block -> (frame, tile): one XCD (blockIdx & 7) works on one contiguous run of items
-    const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + (blockIdx.x >> 3);
+    uint32_t in_run = (blockIdx.x >> 3) + (blockIdx.x & 7u) * (uint32_t)a.stagger;  // (stagger * 7 < chunk: bevwarp_api.hip)
+    if (in_run >= (uint32_t)a.chunk) in_run -= (uint32_t)a.chunk;
+    const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + in_run;
     if (item >= (uint32_t)a.total_tiles) return;
     const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
     const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;

@@ -13,6 +13,7 @@ Each spec patches a COPY of warp_kernels.hip:
     ntload    float taps through non-temporal loads
     noedge    EDGE blocks cost what OUT blocks cost
     ownrow / ownblk   interior tiles forced to row-segment / block ownership (the slant rule's A/B)
+    fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
 import subprocess
@@ -29,8 +30,8 @@ def patch(src, spec):
         assert old in src, (spec, old[:60])
         src = src.replace(old, new, 1)
     if spec == "nostore":
-        rep("    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {  // xs = first pixel of the segment / block\n",
-            "    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) {\n"
+        rep("    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {  // xs = first pixel of the segment / block\n",
+            "    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {\n"
             "        asm volatile(\"\" ::\"v\"(out[0].x), \"v\"(out[0].y), \"v\"(out[0].z), \"v\"(out[0].w));\n        if (y != 12345678) return;\n")
     elif spec == "noload":
         rep("#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n",
@@ -55,8 +56,15 @@ def patch(src, spec):
         rep("            else if (cls == kEdge)\n                edge_s(S1, S2);\n", "            else if (cls == kEdge)\n                fill_s();\n")
     elif spec == "notie":
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
+        rep("            for (int j = 0; j < PPL; j++) tie = min(tie, min(S1[j] & F::kTieMask, S2[j] & F::kTieMask));\n", "            for (int j = 0; j < PPL; j++) tie |= S1[j] >> 31;\n")
     elif spec == "ownrow":  # interior tiles: row segments whatever the slant
         rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = false;\n")
+    elif spec == "fillall":  # every tile costs what an outside tile costs: the launch + prologue + store floor
+        rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (true) {")
+    elif spec == "edgefill":  # tiles the frame's edge crosses cost what outside tiles cost
+        rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || !tile_in) {")
+    elif spec == "infill":  # interior tiles cost what outside tiles cost
+        rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || tile_in) {")
     elif spec == "ownblk":  # interior tiles: blocks whatever the slant
         rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = true;\n")
     else:
