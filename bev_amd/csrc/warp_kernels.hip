@@ -46,13 +46,20 @@ constexpr int pixels_per_lane() { return sizeof(T) == 1 ? 4 : 2; }
 //   RowSeg  one row segment of 64 PPL pixels: pixel j of lane l is (x0 + 64 j + l, y).  A pass reads two source rows of an
 //           axis-aligned map: the interior loop.
 //   BlkSeg  a block of 64 x PPL pixels: pixel j of lane l is (xb + l, y + j), xb = the wave's 64-pixel column strip of the
-//           tile.  Tiles that the frame's edge crosses are cut into these: the edge then runs through a quarter as many
+//           tile.
+//   PatSeg  the same blocks and passes, other lanes: they form a PATCH of (64 / PPL) x PPL pixels and pixel j of lane l is
+//           (xb + (64 / PPL) j + l % (64 / PPL), y + l / (64 / PPL)): one gather instruction covers 16 x 4 (8-bit) /
+//           32 x 2 (float) destination pixels instead of 64 x 1, which halves and better the source rows -- cache lines --
+//           it runs through when the footprint is turned (25 degrees: -22 %, 45 degrees: -31 %; unturned: +8 %).  Tiles that the frame's edge crosses are cut into these: the edge then runs through a quarter as many
 //           passes, and only those pay for guarded taps.
 struct RowSeg {
-    static constexpr bool blk = false;
+    static constexpr bool blk = false, pat = false;
 };
 struct BlkSeg {
-    static constexpr bool blk = true;
+    static constexpr bool blk = true, pat = false;
+};
+struct PatSeg {
+    static constexpr bool blk = true, pat = true;
 };
 // where the exact chain is instantiated: inside a row loop (its matrix loads must stay in the rare branch) or after one
 struct InLoop {
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     constexpr int TW = 64 * PPL;                                 // tile width
     constexpr int kStrips = PPL;                                 // 64-pixel column strips of a tile (block ownership)
     constexpr int BR = PPL;                                      // rows of a block
+    constexpr int PWd = 64 / PPL;                                // lanes per row of a block's patch (BlkSeg)
     constexpr int PBs = (int)sizeof(T) * C;                      // source bytes per pixel
     constexpr int TAPB = INTERP == kLinear ? 2 * PBs : PBs;      // bytes of one row's taps
     constexpr int LOADB = (TAPB + 3) & ~3;                       // loaded per row (whole dwords)
@@ -414,8 +422,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         const double ds = (double)strip;
         CXb = uniform_f64(__builtin_fma(ds, DX, CX)), CYb = uniform_f64(__builtin_fma(ds, DY, CY)), CWb = uniform_f64(__builtin_fma(ds, DW, CW));
     };
-    const double ld = (double)lane;
-    const double cx0 = (m0 * kTwo32) * ld, cy0 = (m3 * kTwo32) * ld, cw0 = m6 * ld;                              // per lane
+    // per lane: the row terms' offset at the lane's first pixel -- `lane` pixels along the row (row segments), or
+    // (lane % PWd, lane / PWd) inside the block's patch.  A tile is processed in one ownership: set below, once it is known.
+    double cx0, cy0, cw0;
 
     // -- byte offsets of FAST rows straight from the high dwords (24-bit multiplies: the host guarantees row stride < 2^24
     // and frames < 2 GiB; a FAST row has 0 <= sx, sy < 2^15, so the low 24 bits of a high dword are 0x380000 + s)
@@ -441,8 +450,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         double Me[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) Me[i] = Mp[i];
-        const int x = kBlk ? xs + lane : x0 + 64 * j + lane;
-        if (kBlk) y += j;
+        constexpr bool kPat = decltype(own)::pat;
+        const int x = kPat ? xs + PWd * j + (lane & (PWd - 1)) : kBlk ? xs + lane : x0 + 64 * j + lane;
+        if (kBlk) y += kPat ? lane / PWd : j;
         const int bx = (int)(fast_div((uint32_t)x, a.bw0_magic, (uint32_t)a.bw0) * (uint32_t)a.bw0);
         double X0, Y0, W0;
         row_terms(Me, bx, y, X0, Y0, W0);
@@ -458,8 +468,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     auto chain_u = [&](auto own, double UX, double UY, double UW, uint32_t (&hx)[PPL], uint32_t (&lx)[PPL], uint32_t (&hy)[PPL], uint32_t (&ly)[PPL],
                        uint32_t& w_first, uint32_t& w_last) __attribute__((always_inline)) -> uint32_t {
         constexpr bool kBlk = decltype(own)::blk;
-        // from pixel j to pixel j + 1 of a lane: 64 pixels along the row, or one row down
-        const double dX = kBlk ? RX : DX, dY = kBlk ? RY : DY, dW = kBlk ? RW : DW;
+        // from pixel j to pixel j + 1 of a lane: 64 pixels along the row (row segments), one row down (blocks), 64 / PPL pixels (patches)
+        constexpr bool kPat = decltype(own)::pat;
+        // (patches: a quarter / half of the per-64-pixel terms -- exact, and three multiplies per pass are cheaper than six more
+        // scalar registers held through the kernel)
+        const double dX = kPat ? DX * (1.0 / PPL) : kBlk ? RX : DX, dY = kPat ? DY * (1.0 / PPL) : kBlk ? RY : DY, dW = kPat ? DW * (1.0 / PPL) : kBlk ? RW : DW;
         double W[PPL], r[PPL];
         W[0] = UW + cw0;
 #pragma unroll
@@ -516,21 +529,23 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
     };
     // (block ownership: y = the block's first row)
-    auto coords_s = [&](int strip, int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) -> int {
-        constexpr bool kBlk = true;
+    auto coords_s = [&](auto own, int strip, int y, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) -> int {
+        constexpr bool kPat = decltype(own)::pat;
+        // lanes / pixels of the block's top-right and bottom-left corners (top-left: pixel 0 of lane 0, bottom-right: pixel PPL-1 of lane 63)
+        constexpr int kTRl = kPat ? PWd - 1 : 63, kTRj = kPat ? PPL - 1 : 0, kBLl = kPat ? 64 - PWd : 0, kBLj = kPat ? 0 : PPL - 1;
         set_strip(strip);
         uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], w_first, w_last;
-        const uint32_t tie = chain(BlkSeg{}, y, hx, lx, hy, ly, w_first, w_last);
-        // -- classify the segment from its ends (pixel 0 of lane 0, pixel PPL-1 of lane 63), in scalar registers
+        const uint32_t tie = chain(own, y, hx, lx, hy, ly, w_first, w_last);
+        // -- classify the block from its four corner pixels, in scalar registers
         auto lane_u32 = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
         const uint32_t hxa = lane_u32(hx[0], 0), hya = lane_u32(hy[0], 0), hxb = lane_u32(hx[PPL - 1], 63), hyb = lane_u32(hy[PPL - 1], 63);
         const uint32_t wa = lane_u32(w_first, 0), wb = lane_u32(w_last, 63);
         const uint32_t ea = (wa >> 20) & 0x7ffu, eb = (wb >> 20) & 0x7ffu;  // 2^-199 .. 2^199: the shared reciprocal is safe
         bool w_ok = ((wa ^ wb) >> 31) == 0 && ea - 824u <= 398u && eb - 824u <= 398u;
         // a block has two more corners (W is linear: one sign at the four corners = one sign inside)
-        const uint32_t hxc = kBlk ? lane_u32(hx[0], 63) : hxa, hyc = kBlk ? lane_u32(hy[0], 63) : hya;
-        const uint32_t hxd = kBlk ? lane_u32(hx[PPL - 1], 0) : hxb, hyd = kBlk ? lane_u32(hy[PPL - 1], 0) : hyb;
-        if (kBlk) w_ok = w_ok && ((wa ^ lane_u32(w_first, 63)) >> 31) == 0 && ((wa ^ lane_u32(w_last, 0)) >> 31) == 0;
+        const uint32_t hxc = lane_u32(hx[kTRj], kTRl), hyc = lane_u32(hy[kTRj], kTRl);
+        const uint32_t hxd = lane_u32(hx[kBLj], kBLl), hyd = lane_u32(hy[kBLj], kBLl);
+        w_ok = w_ok && ((wa ^ lane_u32(kTRj ? w_last : w_first, kTRl)) >> 31) == 0 && ((wa ^ lane_u32(kBLj ? w_last : w_first, kBLl)) >> 31) == 0;
         // source pixel of the two ends (a high dword outside the binade gives |s| >= 2^19: outside every limit below)
         const int sxa = (int)(hxa - kHiBias), sya = (int)(hya - kHiBias), sxb = (int)(hxb - kHiBias), syb = (int)(hyb - kHiBias);
         const int sxc = (int)(hxc - kHiBias), syc = (int)(hyc - kHiBias), sxd = (int)(hxd - kHiBias), syd = (int)(hyd - kHiBias);
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             // the segment), taps need guards
             cls = !(e_ok && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
         }
-        if (tie == 0 && cls != kSlow) fix_ties(BlkSeg{}, xb, y, hx, lx, hy, ly);
+        if (tie == 0 && cls != kSlow) fix_ties(own, xb, y, hx, lx, hy, ly);
         if (__builtin_expect(cls == kFast, 1)) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
         asm volatile("" ::: "memory");  // (the next row's LDS writes cannot pass these reads)
     };
-    auto finish_any = [&](int cls, int xs, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
+    auto finish_any = [&](auto own, int cls, int xs, int y, const uint32_t (&S0)[PPL], const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL], const Bytes<WINB> (&t0)[PPL],
                           const Bytes<WINB> (&t1)[PPL]) __attribute__((always_inline)) {
         if (__builtin_expect(cls == kFast, 1)) {
             finish_s(S0, S1, S2, t0, t1);
@@ -765,7 +780,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             else if (cls == kEdge)
                 edge_s(S1, S2);
             else
-                slow_s(BlkSeg{}, InLoop{}, xs, y);
+                slow_s(own, InLoop{}, xs, y);
         }
     };
 
@@ -775,8 +790,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {  // xs = first pixel of the segment / block
         constexpr bool kBlk = decltype(own)::blk;
         const int seg_px = min(kBlk ? 64 : TW, a.dst_w - xs);  // valid pixels of a row of the segment / block
-        // 8-bit: a lane stores 4 consecutive pixels: of the wave's row (pixels 4 l ..), or of row l / 16 of its block (pixels 4 (l % 16) ..)
-        const int st_row = kBlk ? lane >> 4 : 0, st_x = kBlk ? xs + (lane & 15) * PPL : xs + lane * PPL;
+        // 8-bit: a lane stores the 4 consecutive pixels of its 16-byte unit of the LDS row: pixels 4 l .. of the wave's row; row
+        // l / 16 of its block, pixels 4 (l % 16) ..; or (patches: LDS index 64 j + 16 ly + lx) row (l / 4) % 4, pixels 16 (l / 16) + 4 (l % 4) ..
+        constexpr bool kPat = decltype(own)::pat;
+        const int st_row = kPat ? (lane >> 2) & 3 : kBlk ? lane >> 4 : 0;
+        const int st_x = kPat ? xs + 16 * (lane >> 4) + 4 * (lane & 3) : kBlk ? xs + (lane & 15) * PPL : xs + lane * PPL;
         const int lane_px = max(0, min(PPL, a.dst_w - st_x));  // valid pixels of this lane's store unit
         const bool lane_vec = a.dst_vec_ok && lane_px == PPL;
         if constexpr (sizeof(T) == 1) {  // the lane's 4 pixels = 4 C contiguous bytes, one instruction
@@ -822,7 +840,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             const float* o = reinterpret_cast<const float*>(&out[0]);
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const int px = kBlk ? xs + lane : xs + 64 * j + lane, py = kBlk ? y + j : y;
+                const int px = kPat ? xs + PWd * j + (lane & (PWd - 1)) : kBlk ? xs + lane : xs + 64 * j + lane, py = kPat ? y + lane / PWd : kBlk ? y + j : y;
                 if (px >= a.dst_w || py > y_last) continue;
 #pragma unroll
                 for (int k = 0; k < C; k++) {
@@ -832,12 +850,16 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             }
         } else {
             const int nfl = seg_px * C;  // valid floats of a row of the segment / block
-            constexpr int kRowUnits = 64 * C / 4;  // 16-byte units per 64-pixel row (block ownership)
+            // blocks: the LDS row holds the block's rows one after the other (runs of 64 pixels); patches: pixels in the order
+            // 64 j + PWd ly + lx, i.e. runs of PWd pixels: run n is row n % BR of the block, pixels PWd (n / BR) ..
+            constexpr int kRunUnits = (kPat ? PWd : 64) * C / 4;
+            static_assert(sizeof(T) == 1 || (PWd * C) % 4 == 0, "a run of the patch is a whole number of 16-byte units");
 #pragma unroll
             for (int u = 0; u < NQ; u++) {
                 const int q = u * 64 + lane;
                 if (q >= kVec) continue;
-                const int r = kBlk ? q / kRowUnits : 0, qr = kBlk ? q - r * kRowUnits : q;  // row of the block, unit within the row
+                const int run = kBlk ? q / kRunUnits : 0;
+                const int r = kPat ? run % BR : run, qr = kBlk ? (kPat ? run / BR : 0) * kRunUnits + (q - run * kRunUnits) : q;  // row of the block, unit within the row
                 if (kBlk && y + r > y_last) continue;
                 float* drow = reinterpret_cast<float*>(dframe + (int64_t)(y + r) * a.dst_rs) + (int64_t)xs * C;
                 if (__builtin_expect(a.dst_vec_ok && 4 * qr + 4 <= nfl, 1)) {
@@ -883,12 +905,17 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         const bool c_rep = c_w && (((chx ^ kHiExp) | (chy ^ kHiExp)) >> 20) == 0;
         auto all4 = [](bool v) { return ((uint32_t)__ballot(v) & 0xFu) == 0xFu; };
         tile_out = fill_ok && one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > a.src_w) || all4(csy <= -3) || all4(csy > a.src_h));
-        // source rows a row of the tile runs through, per 64 pixels.  Past ~14 (a 256-pixel segment crossing ~56 rows, e.g.
-        // a 1.4 x minifying map turned by 10 degrees) every lane of a gather instruction sits in a line of its own and the
-        // row segments lose to compact blocks (A/B over rotation angles: DESIGN.md section 6)
-        const int run_top = abs(__builtin_amdgcn_readlane(csy, 1) - __builtin_amdgcn_readlane(csy, 0));
-        const int run_bot = abs(__builtin_amdgcn_readlane(csy, 3) - __builtin_amdgcn_readlane(csy, 2));
-        tile_slanted = max(run_top, run_bot) > 14 * kStrips;
+        // Turned footprints.  A row gather's 64 lanes lie on a source line that crosses dy source rows per 64 destination
+        // pixels -- a cache line each once dy passes the lines the run would touch anyway -- and pixels sqrt(dx^2 + dy^2) / 64 apart;
+        // a 16 x 4 patch of the same 64 pixels crosses a quarter of them.  Measured crossover (A/B over angles and
+        // minifications): patches win when dy (dx^2 + dy^2) / 64^2 > ~15 (5 degrees at 1.4 x minification, 13
+        // degrees at 1 x, 2.5 degrees at 2 x).  Both from the tile's top and bottom edges (corner images).
+        auto edge_slant = [&](int l0, int l1) {
+            const float dy = (float)abs(__builtin_amdgcn_readlane(csy, l1) - __builtin_amdgcn_readlane(csy, l0));
+            const float dx = (float)abs(__builtin_amdgcn_readlane(csx, l1) - __builtin_amdgcn_readlane(csx, l0));
+            return dy * (dx * dx + dy * dy);  // (over the tile's width = kStrips x 64 pixels: kStrips^3 times the per-64-pixel figure)
+        };
+        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) > 15.0f * 4096.0f * (float)(kStrips * kStrips * kStrips);
     }
     // -- the passes of this wave over the tile, in order.
     //   row segments: rows y0 + w + 4 i (neighbouring rows share source lines and run at the same time)
@@ -922,6 +949,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     };
     auto pass_x = [&](const Pass& p) { return x0 + 64 * p.strip; };
 
+    {
+        const bool patches = tile_slanted;  // (slanted tiles: interior and edge-cut alike)
+        const double lx = (double)(patches ? lane & (PWd - 1) : lane), ly = patches ? (double)(lane / PWd) : 0.0;
+        cx0 = __builtin_fma(RX, ly, (m0 * kTwo32) * lx), cy0 = __builtin_fma(RY, ly, (m3 * kTwo32) * lx), cw0 = __builtin_fma(RW, ly, m6 * lx);
+    }
     if (tile_out) {  // every pixel of the tile is the border value
         Pass p;
         if (!first_pass(BlkSeg{}, p)) return;
@@ -1013,23 +1045,25 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             } while (next_pass(own, p));
         }
     };
-    if (tile_in) {
-        if (tile_slanted)
-            interior(BlkSeg{});
-        else
+    // (the branch hints keep the common path -- interior tile, row segments -- the fall-through: with the patch code in the
+    // kernel its layout otherwise costs unturned footprints 3 %)
+    if (__builtin_expect(tile_in, 1)) {
+        if (__builtin_expect(!tile_slanted, 1))
             interior(RowSeg{});
+        else
+            interior(PatSeg{});
         return;
     }
     // -- the frame's edge crosses the tile (or W changes sign in it): blocks with a class each, the same pipeline
-    {
+    auto edge_tile = [&](auto own) __attribute__((always_inline)) {
         Pass p_cur, p_nxt;
-        if (!first_pass(BlkSeg{}, p_nxt)) return;
-        int cls_c = coords_s(p_nxt.strip, p_nxt.y, A0, A1, A2), cls_n = kSlow;
+        if (!first_pass(own, p_nxt)) return;
+        int cls_c = coords_s(own, p_nxt.strip, p_nxt.y, A0, A1, A2), cls_n = kSlow;
         issue_s(cls_c, A0, u0, u1);
         p_cur = p_nxt;
-        bool more = next_pass(BlkSeg{}, p_nxt);
-        if (more) cls_n = coords_s(p_nxt.strip, p_nxt.y, B0, B1, B2);
-        finish_any(cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
+        bool more = next_pass(own, p_nxt);
+        if (more) cls_n = coords_s(own, p_nxt.strip, p_nxt.y, B0, B1, B2);
+        finish_any(own, cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
         while (more) {
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
@@ -1042,14 +1076,18 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             issue_s(cls_c, A0, u0, u1);
             const Pass p_st = p_cur;
             p_cur = p_nxt;
-            more = next_pass(BlkSeg{}, p_nxt);
-            if (more) cls_n = coords_s(p_nxt.strip, p_nxt.y, B0, B1, B2);  // overlaps with the loads in flight
-            store_s(BlkSeg{}, pass_x(p_st), p_st.y, out);
-            finish_any(cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
+            more = next_pass(own, p_nxt);
+            if (more) cls_n = coords_s(own, p_nxt.strip, p_nxt.y, B0, B1, B2);  // overlaps with the loads in flight
+            store_s(own, pass_x(p_st), p_st.y, out);
+            finish_any(own, cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
         }
         read_back(out);
-        store_s(BlkSeg{}, pass_x(p_cur), p_cur.y, out);
-    }
+        store_s(own, pass_x(p_cur), p_cur.y, out);
+    };
+    if (tile_slanted)
+        edge_tile(PatSeg{});
+    else
+        edge_tile(BlkSeg{});
 }
 
 // ===================================================================================================

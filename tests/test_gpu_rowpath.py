@@ -251,3 +251,20 @@ def test_planar_output_of_float_sources(W, kind, c, dw, dh):
         ref = co.warp_perspective(src, M, (dw, dh), interp).reshape(dh, dw, c)
         exp = ref.transpose(2, 0, 1) * scale.astype(np.float32)[:, None, None] + bias.astype(np.float32)[:, None, None]
         np.testing.assert_array_equal(got, exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("deg,zoom,dw,dh", [(30.0, 2.4, 300, 77), (90.0, 0.8, 256, 48), (-12.0, 1.6, 515, 40), (45.0, 1.2, 256, 24)])
+def test_turned_footprints_take_the_patch_layout(W, c, dtype, deg, zoom, dw, dh):
+    """Rotated / minified footprints: interior and edge-cut tiles in the patch lane layout (16 x 4 / 32 x 2 pixels per gather
+    instruction), ragged tile widths and heights, both interpolations, interleaved and planar stores."""
+    sw, sh = 640, 360
+    M = wl.rotated_H(sw, sh, dw, dh, deg, zoom)  # the 515 x 40 / 300 x 77 windows reach past the frame: edge and outside tiles too
+    src = wl.frame(17, sh, sw, dtype, c)
+    for interp in (0, 1):
+        both(W, src, M, (dw, dh), interp)
+    scale, bias = np.linspace(0.5, 2.0, c), np.linspace(-1.0, 1.0, c)
+    got = W.warp_to_planar(torch.from_numpy(src).cuda(), M, (dw, dh), scale=scale, bias=bias).cpu().numpy()
+    ref = co.warp_perspective(src, M, (dw, dh), 1).reshape(dh, dw, c).astype(np.float32)
+    np.testing.assert_array_equal(got, (ref.transpose(2, 0, 1) * scale.astype(np.float32)[:, None, None] + bias.astype(np.float32)[:, None, None]).astype(np.float32))

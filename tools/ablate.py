@@ -12,7 +12,7 @@ Each spec patches a COPY of warp_kernels.hip:
     notie     no tie-window test in the coordinate chain
     ntload    float taps through non-temporal loads
     noedge    EDGE blocks cost what OUT blocks cost
-    ownrow / ownblk   interior tiles forced to row-segment / block ownership (the slant rule's A/B)
+    ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
@@ -58,7 +58,7 @@ def patch(src, spec):
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
         rep("            for (int j = 0; j < PPL; j++) tie = min(tie, min(S1[j] & F::kTieMask, S2[j] & F::kTieMask));\n", "            for (int j = 0; j < PPL; j++) tie |= S1[j] >> 31;\n")
     elif spec == "ownrow":  # interior tiles: row segments whatever the slant
-        rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = false;\n")
+        rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = false && fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
     elif spec == "fillall":  # every tile costs what an outside tile costs: the launch + prologue + store floor
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (true) {")
     elif spec == "edgefill":  # tiles the frame's edge crosses cost what outside tiles cost
@@ -66,7 +66,7 @@ def patch(src, spec):
     elif spec == "infill":  # interior tiles cost what outside tiles cost
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || tile_in) {")
     elif spec == "ownblk":  # interior tiles: blocks whatever the slant
-        rep("        tile_slanted = max(run_top, run_bot) > 14 * kStrips;\n", "        tile_slanted = true;\n")
+        rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
     else:
         raise SystemExit("unknown spec " + spec)
     return src
