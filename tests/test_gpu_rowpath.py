@@ -1,6 +1,6 @@
-"""Parity of the row-classified path of warp_gather (destination tiles a whole number of 64-px evaluation blocks
-wide: 256 px for uint8, 128 px for float32, at least 16 rows) with the CPU oracle: every row class (FAST / OUT /
-EDGE / SLOW), every channel count, border values, rounding ties, W sign changes, degenerate sources.
+"""Parity of warp_rows' tile paths (interior tiles in row segments / patches, edge-cut tiles in blocks / patches, outside
+tiles) with the CPU oracle: every block class (FAST / OUT / EDGE / SLOW), every channel count, border values, rounding
+ties and their redo passes, W sign changes, degenerate sources, batches, planar stores, turned footprints.
 Bit-exact for every dtype (the float kernel keeps the oracle's operation order)."""
 import numpy as np
 import pytest
@@ -190,8 +190,8 @@ def test_row_strides_of_every_alignment(W, sw):
         np.testing.assert_array_equal(got, co.warp_perspective(src, M, (512, 48), 1))
 
 
-# ---- the staged kernel (two launches: LDS-staged interior tiles, then the gather kernel for the rest) is taken from 256
-# ---- tiles up; batches of small frames reach it at sizes the oracle finishes in seconds.
+# ---- launches of hundreds of tiles (per-frame matrices, taller tiles from 2 x the resident workgroups up): batches of small
+# ---- frames reach them at sizes the oracle finishes in seconds.
 def _batch_case(W, dtype_c, sw, sh, dw, dh, B, kind, interp, pad_to=None, border=None):
     c = dtype_c
     frames = np.stack([wl.frame(20 + i, sh, sw, np.uint8, c) for i in range(B)])
@@ -209,24 +209,24 @@ def _batch_case(W, dtype_c, sw, sh, dw, dh, B, kind, interp, pad_to=None, border
 
 
 @pytest.mark.parametrize("c", [1, 2, 3, 4])
-def test_staged_tiles_all_channel_counts(W, c):
+def test_batched_tiles_all_channel_counts(W, c):
     _batch_case(W, c, 640, 360, 512, 256, 8, "keystone", 1)            # 8 x 2 x 16 = 256 tiles, all inside the frame
 
 
-def test_staged_tiles_mixed_with_gather_tiles(W):
-    _batch_case(W, 3, 640, 360, 512, 256, 8, "brno", 1)                 # rotated footprint: (almost) nothing can be staged
+def test_batched_tiles_mixed_footprints(W):
+    _batch_case(W, 3, 640, 360, 512, 256, 8, "brno", 1)                 # turned footprint: patches, edge-cut and outside tiles
     _batch_case(W, 3, 640, 368, 768, 200, 8, "keystone", 1, border=7)  # ragged last group (200 = 12 x 16 + 8), 3 tiles wide
-    _batch_case(W, 3, 1280, 720, 300, 330, 16, "keystone", 1)           # > 1.9 x magnification: boxes exceed the LDS pitch
-    _batch_case(W, 3, 320, 200, 1024, 64, 16, "keystone", 1)            # minification: boxes a few pixels wide
+    _batch_case(W, 3, 1280, 720, 300, 330, 16, "keystone", 1)           # > 1.9 x magnification
+    _batch_case(W, 3, 320, 200, 1024, 64, 16, "keystone", 1)            # strong minification
 
 
-def test_staged_tiles_row_padded_source_and_identity(W):
+def test_batched_tiles_row_padded_source_and_identity(W):
     _batch_case(W, 3, 636, 360, 512, 256, 8, "keystone", 1, pad_to=640)  # row stride 1920 B, rows 16-byte aligned, width not
     _batch_case(W, 3, 640, 360, 512, 256, 8, "identity", 1)              # integer coordinates: every pixel on a tie boundary
     _batch_case(W, 4, 640, 360, 512, 256, 8, "identity", 1)
 
 
-def test_staged_tiles_planar_output(W):
+def test_batched_tiles_planar_output(W):
     B, sw, sh, dw, dh = 8, 640, 360, 512, 256
     frames = np.stack([wl.frame(40 + i, sh, sw, np.uint8) for i in range(B)])
     Ms = np.stack([wl.jitter_H(wl.keystone_H(sw, sh, dw, dh), i) for i in range(B)])

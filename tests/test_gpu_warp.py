@@ -45,7 +45,7 @@ SHAPES = [
     ("brno", 192, 108, 37, 53),         # ragged destination
     ("keystone", 100, 60, 300, 9),      # height < 16: evaluation blocks are 113 wide
     ("brno", 64, 36, 70, 1),
-    ("brno", 853, 481, 200, 120),       # source width not a multiple of 4: unstaged path
+    ("brno", 853, 481, 200, 120),       # source row stride not a multiple of 4: the two tap rows of a window differ in alignment
 ]
 
 
@@ -101,7 +101,7 @@ def test_row_padding_and_frame_views(W):
     sw, sh, dw, dh = 600, 300, 128, 96
     M = wl.synth_brno_H(1920, 1080, dw, dh) @ np.diag([1920 / sw, 1080 / sh, 1.0])
     big = torch.from_numpy(wl.frame(7, sh, sw + 40, np.uint8)).cuda()
-    view = big[:, 8:8 + sw]  # rows keep the pitch of the parent: not 16-byte aligned -> unstaged path
+    view = big[:, 8:8 + sw]  # rows keep the pitch of the parent: not 16-byte aligned
     assert not view.is_contiguous()
     got = W.warp_perspective(view, M, (dw, dh)).cpu().numpy()
     check(got, co.warp_perspective(np.ascontiguousarray(view.cpu().numpy()), M, (dw, dh)))
@@ -149,7 +149,7 @@ def test_degenerate_homographies(W):
 
 
 def test_magnification_and_minification_extremes(W):
-    """x8 zoom (tiny source region per tile) and /6 shrink (region exceeds the LDS budget -> unstaged tiles)."""
+    """x8 zoom (tiny source region per tile) and /6 shrink (every tap pair in a cache line of its own)."""
     src = wl.frame(4, 720, 1280, np.uint8)
     Z = np.array([[8.0, 0, -300.0], [0, 8.0, -200.0], [0, 0, 1]])
     check(run_gpu(W, src, Z, (512, 256), 1), co.warp_perspective(src, Z, (512, 256), 1))
