@@ -268,3 +268,21 @@ def test_turned_footprints_take_the_patch_layout(W, c, dtype, deg, zoom, dw, dh)
     got = W.warp_to_planar(torch.from_numpy(src).cuda(), M, (dw, dh), scale=scale, bias=bias).cpu().numpy()
     ref = co.warp_perspective(src, M, (dw, dh), 1).reshape(dh, dw, c).astype(np.float32)
     np.testing.assert_array_equal(got, (ref.transpose(2, 0, 1) * scale.astype(np.float32)[:, None, None] + bias.astype(np.float32)[:, None, None]).astype(np.float32))
+
+
+@pytest.mark.parametrize("c,dtype", [(3, np.uint8), (1, np.uint8), (3, np.float32), (2, np.float32)])
+def test_turned_footprints_through_unaligned_views(W, c, dtype):
+    """Patch layout with a source view whose frames / rows are not 4-byte aligned and a destination view that admits no wide
+    store (odd base and row stride): the element-store path of every lane."""
+    sw, sh, dw, dh = 637, 355, 301, 45
+    M = wl.rotated_H(sw, sh, dw, dh, 33.0, 1.7)  # reaches past the frame on two sides
+    src = wl.frame(23, sh, sw, dtype, c)
+    src_big = torch.zeros((sh, sw + 3, c), dtype=torch.from_numpy(src).dtype, device="cuda")
+    src_big[:, 1:1 + sw] = torch.from_numpy(src).cuda()
+    for interp in (0, 1):
+        out_big = torch.full((dh, dw + 5, c), 77, dtype=src_big.dtype, device="cuda")
+        W.warp_perspective(src_big[:, 1:1 + sw], M, (dw, dh), flags=interp, out=out_big[:, 3:3 + dw])
+        torch.cuda.synchronize()
+        got = out_big.cpu().numpy()
+        np.testing.assert_array_equal(got[:, 3:3 + dw], co.warp_perspective(src, M, (dw, dh), interp).reshape(dh, dw, c))
+        assert (got[:, :3] == 77).all() and (got[:, 3 + dw:] == 77).all()  # nothing written outside the view
