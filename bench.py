@@ -387,6 +387,32 @@ def config4(dev):
     return res
 
 
+def composite_config(dev):
+    """composite_bev_img (bev/tool/compo.py:26-49) -- one launch against three warps + the blend launch."""
+    from bev_amd import warp
+    from bev_amd.compo import composite_bev_img, composite_reg_img
+    from bev_amd.homo import homo_from_KRt
+    from tests import workloads as wl
+    K = np.array([[1200.0, 0, 959.5], [0, 1190.0, 539.5], [0, 0, 1.0]])
+    c, s_ = np.cos(0.9), np.sin(0.9)
+    RT = np.array([[1, 0, 0, 0.0], [0, c, -s_, 2.0], [0, s_, c, 14.0], [0, 0, 0, 1.0]])
+    H_world2bev = np.array([[0.0, 24.0, 512.0], [-24.0, 0.0, 900.0], [0.0, 0.0, 1.0]])
+    H_img2world_fix = np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)) @ np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])
+    bg, fg, mask = (torch.from_numpy(wl.frame(i, 1080, 1920, np.uint8)).to(dev) for i in (0, 1, 2))
+    one = event_times(lambda: composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 1024, 1024), 100, 10)
+    Hb = H_world2bev.dot(H_img2world_fix)
+    Hc = H_world2bev.dot(np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)))
+
+    def three():
+        return composite_reg_img(warp.warp_perspective(bg, Hb, (1024, 1024)), warp.warp_perspective(fg, Hc, (1024, 1024)), warp.warp_perspective(mask, Hc, (1024, 1024)))
+
+    thr = event_times(three, 100, 10)
+    same = bool(torch.equal(three(), composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 1024, 1024)[0]))
+    return {"workload": "composite_bev_img: 1080p background + 1080p foreground + mask -> one 1024x1024 uint8 composite (device resident)",
+            "one_launch_us": round(float(np.median(one)) * 1e6, 1), "three_warps_plus_blend_us": round(float(np.median(thr)) * 1e6, 1),
+            "one_launch_equals_three_warps_plus_blend": same}
+
+
 def pipeline_config(dev):
     """PCIe-inclusive frames/s of 1080p -> 1024^2 uint8: one call at a time against the three-stream pipeline (never `value`)."""
     from bev_amd import warp
@@ -486,7 +512,7 @@ def main():
     if world == 1 and not args.no_configs:
         cfg = {}
         for name, fn in (("configs[0]", lambda: config0(dev)), ("configs[2]", lambda: config2(dev)), ("configs[3]", lambda: config3(args, dev, shard.barrier)),
-                         ("configs[4]", lambda: config4(dev)), ("pcie_pipeline", lambda: pipeline_config(dev))):
+                         ("configs[4]", lambda: config4(dev)), ("f3_composite", lambda: composite_config(dev)), ("pcie_pipeline", lambda: pipeline_config(dev))):
             try:
                 cfg[name] = fn()
             except Exception as e:  # a failing side measurement must not lose the headline line
