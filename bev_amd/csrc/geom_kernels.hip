@@ -114,7 +114,7 @@ __device__ __forceinline__ Quad corners_of(double cx, double cy, double w, doubl
 // ping-pong in LDS (vertex-major, one column per thread: dynamic indexing without scratch memory); the signed
 // distance of a vertex is computed once and carried to the next edge test.  Same expressions, same order as
 // oracle/warp_oracle.c.
-constexpr int kIouThreads = 256;
+constexpr int kIouThreads = 64;
 __device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B, double* __restrict__ lds, int tid) {
     auto P = [&](int buf, int xy, int k) -> double& { return lds[((buf * 2 + xy) * 8 + k) * kIouThreads + tid]; };
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ double pair_iou(const double (&A)[5], const T* __rest
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
-    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];  // 64 KiB: two vertex lists per thread
+    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];  // 16 KiB: two vertex lists per thread
     const int j = blockIdx.x * blockDim.x + threadIdx.x;  // column (box of b) -> coalesced stores
     const int i = blockIdx.y;
     if (j >= nb) return;
@@ -327,7 +327,7 @@ hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, i
                            hipStream_t stream) {
     if (na == 0 || nb == 0) return hipSuccess;
     (void)hipGetLastError();
-    const dim3 block(256), grid((nb + 255) / 256, na);
+    const dim3 block(kIouThreads), grid((nb + kIouThreads - 1) / kIouThreads, na);
     if (dtype == 2)
         hipLaunchKernelGGL(rbox_iou_kernel<double>, grid, block, 0, stream, (const double*)a, na, a_stride, (const double*)b, nb, b_stride, (double*)out);
     else
