@@ -52,16 +52,19 @@ _H2D, _D2H = 1, 2  # hipMemcpyHostToDevice / hipMemcpyDeviceToHost
 
 class FramePipeline:
     def __init__(self, src_hw, channels, M, dsize, flags=_warp.INTER_LINEAR, depth=3, dtype=torch.uint8, planar=False, scale=1.0 / 255.0, bias=0.0,
-                 download=True, device="cuda"):
+                 download=True, device="cuda", zero_copy_out=True):
         """src_hw (H, W) of the decoded frames; M the forward homography (as for warpPerspective); dsize (u_size, v_size).
         download=False leaves the BEV frames on the device (results are device tensors valid until `depth` further frames
-        have been submitted)."""
+        have been submitted).  zero_copy_out (with download): the kernel stores the BEV frame straight into the pinned host
+        slot over PCIe -- no device copy of it, no D2H copy behind the kernel (on boxes where the two copy directions share an
+        engine that copy serialises with the next frame's upload)."""
         if depth < 2:
             raise ValueError("depth must be >= 2 (one slot in flight per stage boundary)")
         self.device = torch.device(device)
         self.H, self.W, self.C = int(src_hw[0]), int(src_hw[1]), int(channels)
         self.dw, self.dh = int(dsize[0]), int(dsize[1])
         self.flags, self.depth, self.planar, self.scale, self.bias, self.download = flags, depth, planar, scale, bias, download
+        self.zero_copy_out = bool(zero_copy_out and download)
         out_shape = (self.C, self.dh, self.dw) if planar else (self.dh, self.dw, self.C)
         out_dtype = torch.float32 if planar else dtype
         self.h_in = [torch.empty((self.H, self.W, self.C), dtype=dtype, pin_memory=True) for _ in range(depth)]
@@ -91,7 +94,7 @@ class FramePipeline:
         lib = _lib.load()
         self._launch = []
         for slot in range(depth):
-            s, d = self.d_in[slot], self.d_out[slot]
+            s, d = self.d_in[slot], (self.h_out[slot] if self.zero_copy_out else self.d_out[slot])  # (pinned host memory is device-addressable)
             if planar:
                 sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (self.C,)))
                 bi = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, dtype=np.float64), (self.C,)))
@@ -132,7 +135,7 @@ class FramePipeline:
         Blocks only if that slot's previous frame has not left the device yet."""
         slot = self.n_in % self.depth
         if self.n_in >= self.depth:
-            _ok(_hip_rt().hipEventSynchronize((self.ev_down if self.download else self.ev_run)[slot]))  # its previous occupant is through
+            _ok(_hip_rt().hipEventSynchronize((self.ev_down if self.download and not self.zero_copy_out else self.ev_run)[slot]))  # its previous occupant is through
         return self.h_in[slot].numpy()
 
     def commit(self):
@@ -145,7 +148,7 @@ class FramePipeline:
         fn, args = self._launch[slot]
         _lib.check(fn(*args))
         _ok(hip.hipEventRecord(self.ev_run[slot], self.s_run))
-        if self.download:
+        if self.download and not self.zero_copy_out:
             _ok(hip.hipStreamWaitEvent(self.s_down, self.ev_run[slot], 0))
             _ok(hip.hipMemcpyAsync(self.h_out[slot].data_ptr(), self.d_out[slot].data_ptr(), self._out_bytes, _D2H, self.s_down))
             _ok(hip.hipEventRecord(self.ev_down[slot], self.s_down))
@@ -166,7 +169,7 @@ class FramePipeline:
         committed) or the device tensor.  Blocks until that frame is through."""
         slot = self.pending.popleft()
         if self.download:
-            _ok(_hip_rt().hipEventSynchronize(self.ev_down[slot]))
+            _ok(_hip_rt().hipEventSynchronize((self.ev_run if self.zero_copy_out else self.ev_down)[slot]))
             return self.h_out[slot].numpy()
         _ok(_hip_rt().hipEventSynchronize(self.ev_run[slot]))
         return self.d_out[slot]

@@ -260,11 +260,15 @@ def test_frame_pipeline_matches_resident_path():
     M = wl.synth_brno_H(sw, sh, dw, dh)
     frames = [wl.frame(60 + i, sh, sw, np.uint8) for i in range(7)]
     exp = [co.warp_perspective(f, M, (dw, dh), 1) for f in frames]
-    pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=3)
-    got = [r.copy() for r in pipe.run(frames)]  # (results are views of a pinned ring)
-    assert len(got) == len(frames)
-    for g, e in zip(got, exp):
-        np.testing.assert_array_equal(g, e)
+    for zc in (True, False):  # the kernel storing straight into the pinned host slot / a device frame copied down behind it
+        pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=3, zero_copy_out=zc)
+        got = [r.copy() for r in pipe.run(frames)]  # (results are views of a pinned ring)
+        assert len(got) == len(frames)
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+    pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=2, planar=True, scale=0.5, bias=1.0)  # planar frames into host slots
+    for g, f in zip(pipe.run(frames[:3]), frames[:3]):
+        np.testing.assert_array_equal(g, W.warp_to_planar(torch.from_numpy(f).cuda(), M, (dw, dh), scale=0.5, bias=1.0).cpu().numpy())
     # zero-copy ingest (the decoder writes into the pinned slot), results left on the device, planar egress
     pipe = FramePipeline((sh, sw), 3, M, (dw, dh), depth=2, planar=True, scale=[1 / 255.0, 0.5, 2.0], bias=[0.0, -1.0, 3.5], download=False)
     for i, f in enumerate(frames[:4]):
