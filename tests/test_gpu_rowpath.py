@@ -286,3 +286,41 @@ def test_turned_footprints_through_unaligned_views(W, c, dtype):
         got = out_big.cpu().numpy()
         np.testing.assert_array_equal(got[:, 3:3 + dw], co.warp_perspective(src, M, (dw, dh), interp).reshape(dh, dw, c))
         assert (got[:, :3] == 77).all() and (got[:, 3 + dw:] == 77).all()  # nothing written outside the view
+
+
+def _random_homography(rng, sw, sh, dw, dh):
+    """src -> dst map of a random similarity-plus-perspective window: rotation, 0.4 .. 3 x scale, mild keystone, a shift that
+    may push part of the window out of the frame."""
+    ang = rng.uniform(-np.pi, np.pi) if rng.random() < 0.7 else rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2])
+    zoom = float(np.exp(rng.uniform(np.log(0.4), np.log(3.0))))
+    c, s = np.cos(ang) * zoom, np.sin(ang) * zoom
+    A = np.array([[c, -s, 0.0], [s, c, 0.0], [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]])
+    T0 = np.array([[1, 0, -(dw - 1) / 2.0], [0, 1, -(dh - 1) / 2.0], [0, 0, 1.0]])
+    T1 = np.array([[1, 0, (sw - 1) / 2.0 + rng.uniform(-0.4, 0.4) * sw], [0, 1, (sh - 1) / 2.0 + rng.uniform(-0.4, 0.4) * sh], [0, 0, 1.0]])
+    if rng.random() < 0.25:  # integer-valued similarity: every coordinate on a tie boundary
+        A = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]) * [[1], [1], [1]]
+        T1 = np.round(T1)
+        T0 = np.round(T0)
+    return np.linalg.inv(T1 @ A @ T0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_homographies_all_formats(W, seed):
+    """Seeded sweep: random windows (turned, scaled, keystoned, partly outside the frame, tie-heavy), random sizes, every
+    format and both interpolations, single frames and small batches with per-frame matrices."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(10):
+        sw, sh = int(rng.integers(40, 700)), int(rng.integers(30, 400))
+        dw, dh = int(rng.integers(1, 600)), int(rng.integers(1, 90))
+        c = int(rng.integers(1, 5))
+        dtype = np.uint8 if rng.random() < 0.6 else np.float32
+        interp = int(rng.integers(0, 2))
+        B = int(rng.choice([1, 1, 3]))
+        Ms = np.stack([_random_homography(rng, sw, sh, dw, dh) for _ in range(B)])
+        frames = np.stack([wl.frame(100 * seed + case + i, sh, sw, dtype, c) for i in range(B)])
+        border = None if rng.random() < 0.5 else [float(rng.integers(0, 200))] * c
+        got = W.warp_perspective(torch.from_numpy(frames).cuda(), Ms, (dw, dh), flags=interp, border_value=border).cpu().numpy()
+        for i in range(B):
+            exp = co.warp_perspective(frames[i], Ms[i], (dw, dh), interp, border_value=0 if border is None else border)
+            np.testing.assert_array_equal(got[i].reshape(exp.shape), exp, err_msg="seed %d case %d frame %d: %dx%d -> %dx%d c=%d %s interp=%d" % (
+                seed, case, i, sw, sh, dw, dh, c, np.dtype(dtype).name, interp))
