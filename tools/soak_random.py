@@ -37,6 +37,16 @@ for seed in range(first, first + count):
                 bad += 1
                 print("MISMATCH seed %d case %d frame %d: %dx%d -> %dx%d c=%d %s interp=%d (%d pixels differ)" % (
                     seed, case, i, sw, sh, dw, dh, c, np.dtype(dtype).name, interp, int((got[i].reshape(exp.shape) != exp).any(-1).sum() if exp.ndim == 3 else (got[i].reshape(exp.shape) != exp).sum())))
+        if interp == 1 or rng.random() < 0.5:  # the planar store path of the same launch shape
+            sc, bi = np.linspace(0.5, 2.0, c), np.linspace(-1.0, 1.0, c)
+            pl = W.warp_to_planar(torch.from_numpy(frames).cuda(), Ms, (dw, dh), scale=sc, bias=bi, flags=interp, border_value=border).cpu().numpy()
+            for i in range(B):
+                exp = co.warp_perspective(frames[i], Ms[i], (dw, dh), interp, border_value=0 if border is None else border, nthreads=16).reshape(dh, dw, c)
+                ref = (exp.astype(np.float32).transpose(2, 0, 1) * sc.astype(np.float32)[:, None, None] + bi.astype(np.float32)[:, None, None]).astype(np.float32)
+                n += 1
+                if not np.array_equal(pl[i].reshape(ref.shape), ref):
+                    bad += 1
+                    print("PLANAR MISMATCH seed %d case %d frame %d: %dx%d -> %dx%d c=%d %s interp=%d" % (seed, case, i, sw, sh, dw, dh, c, np.dtype(dtype).name, interp))
     if bad > 5:
         break
 print("soak: %d warps compared, %d mismatches" % (n, bad))
