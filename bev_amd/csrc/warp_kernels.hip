@@ -908,14 +908,16 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         // Turned footprints.  A row gather's 64 lanes lie on a source line that crosses dy source rows per 64 destination
         // pixels -- a cache line each once dy passes the lines the run would touch anyway -- and pixels sqrt(dx^2 + dy^2) / 64 apart;
         // a 16 x 4 patch of the same 64 pixels crosses a quarter of them.  Measured crossover (A/B over angles and
-        // minifications): patches win when dy (dx^2 + dy^2) / 64^2 > ~15 (5 degrees at 1.4 x minification, 13
+        // minifications): 8-bit patches win when dy (dx^2 + dy^2) / 64^2 > ~15 (5 degrees at 1.4 x minification, 13
         // degrees at 1 x, 2.5 degrees at 2 x).  Both from the tile's top and bottom edges (corner images).
         auto edge_slant = [&](int l0, int l1) {
             const float dy = (float)abs(__builtin_amdgcn_readlane(csy, l1) - __builtin_amdgcn_readlane(csy, l0));
             const float dx = (float)abs(__builtin_amdgcn_readlane(csx, l1) - __builtin_amdgcn_readlane(csx, l0));
             return dy * (dx * dx + dy * dy);  // (over the tile's width = kStrips x 64 pixels: kStrips^3 times the per-64-pixel figure)
         };
-        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) > 15.0f * 4096.0f * (float)(kStrips * kStrips * kStrips);
+        // (float pixels: 32 x 2 patches cost an unturned footprint nothing and win from the first degrees on: threshold 2)
+        constexpr float kSlantThr = sizeof(T) == 1 ? 15.0f : 2.0f;
+        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) > kSlantThr * 4096.0f * (float)(kStrips * kStrips * kStrips);
     }
     // -- the passes of this wave over the tile, in order.
     //   row segments: rows y0 + w + 4 i (neighbouring rows share source lines and run at the same time)
