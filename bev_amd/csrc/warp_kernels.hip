@@ -915,8 +915,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             const float dx = (float)abs(__builtin_amdgcn_readlane(csx, l1) - __builtin_amdgcn_readlane(csx, l0));
             return dy * (dx * dx + dy * dy);  // (over the tile's width = kStrips x 64 pixels: kStrips^3 times the per-64-pixel figure)
         };
-        // (float pixels: 32 x 2 patches cost an unturned footprint nothing and win from the first degrees on: threshold 2)
-        constexpr float kSlantThr = sizeof(T) == 1 ? 15.0f : 2.0f;
+        // The crossover scales with the bytes of a pixel (the lines a 64-pixel run touches anyway): 45 / bytes -- 15 for 8-bit
+        // RGB, 11 for RGBA, 45 for grey, < 4 for float RGB (whose 32 x 2 patches cost an unturned footprint nothing).
+        // (Single-channel float is the exception: its 32 x 2 patches lose to row segments up to ~20 degrees: 45.)
+        constexpr float kSlantThr = sizeof(T) == 4 && C == 1 ? 45.0f : 45.0f / (float)PBs;
         tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) > kSlantThr * 4096.0f * (float)(kStrips * kStrips * kStrips);
     }
     // -- the passes of this wave over the tile, in order.
