@@ -49,4 +49,24 @@ for seed in range(first, first + count):
                     print("PLANAR MISMATCH seed %d case %d frame %d: %dx%d -> %dx%d c=%d %s interp=%d" % (seed, case, i, sw, sh, dw, dh, c, np.dtype(dtype).name, interp))
     if bad > 5:
         break
-print("soak: %d warps compared, %d mismatches" % (n, bad))
+# the one-launch composite (f3) against three device warps + the blend launch, on random window pairs
+from bev_amd.compo import composite_bev_img, composite_reg_img  # noqa: E402
+nc = badc = 0
+RT = np.eye(4)
+RT[2, 3] = 1.0  # homo_from_KRt(K, Rt_homo=RT) == K: the camera map is then inv(K)
+for seed in range(first, first + count):
+    rng = np.random.default_rng(5000 + seed)
+    for case in range(4):
+        sw, sh = int(rng.integers(40, 700)), int(rng.integers(30, 400))
+        fw, fh = (sw, sh) if rng.random() < 0.5 else (int(rng.integers(40, 500)), int(rng.integers(30, 300)))
+        dw, dh = int(rng.integers(1, 500)), int(rng.integers(1, 120))
+        c = int(rng.choice([1, 3, 3, 4]))
+        M_bg, M_cam = _random_homography(rng, sw, sh, dw, dh), _random_homography(rng, fw, fh, dw, dh)
+        bg, fg, mk = (torch.from_numpy(wl.frame(7 * seed + case + k, h_, w_, np.uint8, c)).cuda() for k, (w_, h_) in enumerate(((sw, sh), (fw, fh), (fw, fh))))
+        one, _ = composite_bev_img(bg, fg, mk, np.eye(3), M_bg, np.linalg.inv(M_cam), RT, dw, dh)
+        three = composite_reg_img(W.warp_perspective(bg, M_bg, (dw, dh)), W.warp_perspective(fg, M_cam, (dw, dh)), W.warp_perspective(mk, M_cam, (dw, dh)))
+        nc += 1
+        if not torch.equal(one.reshape(three.shape), three):
+            badc += 1
+            print("COMPOSITE MISMATCH seed %d case %d: bg %dx%d fg %dx%d -> %dx%d c=%d (%d bytes differ)" % (seed, case, sw, sh, fw, fh, dw, dh, c, int((one.reshape(three.shape) != three).sum())))
+print("soak: %d warps compared, %d mismatches; %d composites compared, %d mismatches" % (n, bad, nc, badc))
