@@ -165,6 +165,12 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // Frames of one launch usually share a footprint: left alone, all eight XCDs would be in the same part of a frame --
     // outside tiles (store-bound) or interior tiles (latency-bound) -- at the same time.  XCD k starts k/8 of a frame in.
     a.stagger = chunk >= a.tiles_per_frame ? a.tiles_per_frame / 8 : 0;
+    // one resident round of half-height workgroups at the end of launches of at least four rounds (tile_h / 2 stays a multiple of 4)
+    const int64_t round_per_xcd = resident / 8;
+    a.tail_split = (a.tile_h % 8 == 0 && chunk >= 4 * round_per_xcd) ? (int)round_per_xcd : 0;
+#ifdef BEVWARP_TAIL_SPLIT  // experiments only
+    a.tail_split = chunk > BEVWARP_TAIL_SPLIT ? BEVWARP_TAIL_SPLIT : 0;
+#endif
     // division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
     auto magic = [](uint64_t n_max, uint32_t d) -> uint32_t {
         return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u;

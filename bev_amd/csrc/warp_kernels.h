@@ -22,6 +22,7 @@ struct WarpArgs {
     int tiles_x, tiles_per_frame;
     int tile_h;                  // rows per workgroup (a multiple of the 4 rows one pass of its waves covers)
     int chunk;                   // items per XCD: grid = 8 * chunk
+    int tail_split;              // the last tail_split tiles of every XCD's dispatch order run as two half-height workgroups
     int stagger;                 // XCD k walks its run starting k * stagger items in (0: all start at the run's first item)
     int dst_vec_ok;              // destination layout admits the wide stores
     float bval_f[4];

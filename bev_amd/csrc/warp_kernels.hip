@@ -371,20 +371,30 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     } clock_stamp;
 #endif
     // block -> (frame, tile): one XCD (blockIdx & 7) works on one contiguous run of items
-    uint32_t in_run = (blockIdx.x >> 3) + (blockIdx.x & 7u) * (uint32_t)a.stagger;  // (stagger * 7 < chunk: bevwarp_api.hip)
+    // The last `tail_split` tiles an XCD dispatches are cut into an upper and a lower half, one workgroup each: the launch's
+    // tail is then made of half-length workgroups.
+    uint32_t seq = blockIdx.x >> 3;  // dispatch order within the XCD
+    int half = -1;
+    if (seq >= (uint32_t)(a.chunk - a.tail_split)) {
+        const uint32_t j = seq - (uint32_t)(a.chunk - a.tail_split);
+        seq = (uint32_t)(a.chunk - a.tail_split) + (j >> 1);
+        half = (int)(j & 1u);
+    }
+    uint32_t in_run = seq + (blockIdx.x & 7u) * (uint32_t)a.stagger;  // (stagger * 7 < chunk: bevwarp_api.hip)
     if (in_run >= (uint32_t)a.chunk) in_run -= (uint32_t)a.chunk;
     const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + in_run;
     if (item >= (uint32_t)a.total_tiles) return;
     const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
     const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;
     const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;
-    const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h;
+    const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h + (half == 1 ? a.tile_h / 2 : 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
     const uint8_t* __restrict__ frame = a.src + (int64_t)frame_idx * a.src_fs;
     uint8_t* __restrict__ dframe = a.dst + (int64_t)frame_idx * a.dst_fs;
     const double* __restrict__ M = a.minv + (int64_t)frame_idx * a.m_stride;
-    const int y_last = min(y0 + a.tile_h, a.dst_h) - 1;
+    const int y_last = min(y0 + (half >= 0 ? a.tile_h / 2 : a.tile_h), a.dst_h) - 1;
+    if (y0 > y_last) return;  // (the lower half of a ragged last tile may be empty)
 
     SrcView view;
     view.frame = frame;
@@ -1262,7 +1272,7 @@ int resident_workgroups(int dtype, int channels, int interp) {
 
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream) {
     (void)hipGetLastError();  // a stale error left by the host framework is not this call's
-    const dim3 grid((unsigned)(8 * a.chunk));
+    const dim3 grid((unsigned)(8 * (a.chunk + a.tail_split)));
     if (dtype == 0)
         launch_t<uint8_t>(a, channels, interp, grid, stream);
     else
