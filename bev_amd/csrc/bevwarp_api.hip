@@ -165,9 +165,10 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // Frames of one launch usually share a footprint: left alone, all eight XCDs would be in the same part of a frame --
     // outside tiles (store-bound) or interior tiles (latency-bound) -- at the same time.  XCD k starts k/8 of a frame in.
     a.stagger = chunk >= a.tiles_per_frame ? a.tiles_per_frame / 8 : 0;
-    // one resident round of half-height workgroups at the end of launches of at least four rounds (tile_h / 2 stays a multiple of 4)
+    // one resident round of half-height workgroups at the end of launches of at least two rounds (tile_h / 2 stays a multiple
+    // of 4); measured neutral to -2.5 % on footprints whose tiles cost alike, -8..-14 % on a perspective BEV from 12 frames up
     const int64_t round_per_xcd = resident / 8;
-    a.tail_split = (a.tile_h % 8 == 0 && chunk >= 4 * round_per_xcd) ? (int)round_per_xcd : 0;
+    a.tail_split = (a.tile_h % 8 == 0 && chunk >= 2 * round_per_xcd) ? (int)round_per_xcd : 0;
 #ifdef BEVWARP_TAIL_SPLIT  // experiments only
     a.tail_split = chunk > BEVWARP_TAIL_SPLIT ? BEVWARP_TAIL_SPLIT : 0;
 #endif
