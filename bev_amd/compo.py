@@ -40,6 +40,8 @@ def gray_bgr(fg):
     """cv2.cvtColor(cv2.cvtColor(fg, COLOR_BGR2GRAY), COLOR_GRAY2BGR) for uint8 BGR (the reference's bw_mode, compo.py:13-14):
     OpenCV's 14-bit fixed point, gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, replicated to three channels.
     (Restated from OpenCV's color conversion; parity unpinned -- the reference holds no fixture for it.)"""
+    if fg.dim() != 3 or fg.shape[2] != 3:
+        raise ValueError("bw_mode needs a 3-channel BGR foreground (cv2.COLOR_BGR2GRAY), got shape %s" % (tuple(fg.shape),))
     f = fg.to(torch.int32)
     g = ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).to(torch.uint8)
     return g[..., None].expand(-1, -1, 3).contiguous()

@@ -119,6 +119,13 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     if (src_w > 32767 || src_h > 32767) return BEVWARP_ERR_TOO_LARGE;
     if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31) || src_row_stride >= (1 << 24)) return BEVWARP_ERR_TOO_LARGE;  // (kernels use 24-bit multiplies)
     if (batch == 0) return BEVWARP_OK;
+    {  // the kernel reads taps of a frame while other workgroups store into it: an in-place call would corrupt silently
+        const uintptr_t s0 = (uintptr_t)src, s1 = s0 + (uint64_t)(batch - 1) * src_frame_stride + (uint64_t)(src_h - 1) * src_row_stride + (uint64_t)src_w * pix;
+        const uint64_t dst_frame_bytes = po ? (uint64_t)(channels - 1) * po->plane_stride + (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * 4
+                                            : (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * pix;
+        const uintptr_t d0 = (uintptr_t)dst, d1 = d0 + (uint64_t)(batch - 1) * dst_frame_stride + dst_frame_bytes;
+        if (s0 < d1 && d0 < s1) return BEVWARP_ERR_BAD_ARG;
+    }
 
     WarpArgs a;
     memset(&a, 0, sizeof(a));

@@ -289,6 +289,8 @@ __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, in
     }
     float w00 = 0, w01 = 0, w10 = 0, w11 = 0;
     if constexpr (sizeof(T) == 4) weights_f32(fx, fy, w00, w01, w10, w11);
+    // all four taps outside: the reference stores the border value itself (for 8-bit pixels the blend gives it back anyway)
+    const bool all_out = sx >= a.w || sx + 1 < 0 || sy >= a.h || sy + 1 < 0;
 #pragma unroll
     for (int k = 0; k < C; k++) {
         const T b = border_of<T>(a, k);
@@ -299,7 +301,7 @@ __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, in
         if constexpr (sizeof(T) == 1)
             out.packed |= blend_u8(v00, v01, v10, v11, fx, fy) << (8 * k);
         else
-            out.v[k] = blend_f32(v00, v01, v10, v11, w00, w01, w10, w11);
+            out.v[k] = all_out ? b : blend_f32(v00, v01, v10, v11, w00, w01, w10, w11);
     }
     return out;
 }
@@ -444,11 +446,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     const uint32_t kOff = fa - 0x380000u * (rs32 + (uint32_t)PBs);
     const uint8_t* dummy = reinterpret_cast<const uint8_t*>(M);  // 72 valid bytes: what rows that are not FAST "load"
 
-    // OUT rows may be filled with the border value when blending four border taps gives it back exactly:
-    // always for 8-bit (the fixed-point weights sum to 2^15) and nearest; for float bilinear only for +0
-    bool fill_ok = true;
-    if (sizeof(T) == 4 && INTERP == kLinear)
-        for (int k = 0; k < C; k++) fill_ok = fill_ok && __float_as_uint(a.bval_f[k]) == 0u;
+    // OUT rows / tiles are filled with the border value: a pixel whose four taps all lie outside the frame IS the border
+    // value in the reference (remapBilinear's "fully outside" path stores it directly -- float pixels too, no 4-term blend)
 
     enum { kFast = 0, kOut = 1, kEdge = 2, kSlow = 3 };
     // the reference's chain for pixel j of this lane (rare: tie windows, SLOW rows); the matrix is re-read here so that the
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             const bool out = sx_hi <= -3 || sx_lo > a.src_w || sy_hi <= -3 || sy_lo > a.src_h;
             // kEdge: W of one sign and both ends representable => every pixel between them is (the map is monotone along
             // the segment), taps need guards
-            cls = !(e_ok && w_ok) ? kSlow : ((out && fill_ok) ? kOut : kEdge);
+            cls = !(e_ok && w_ok) ? kSlow : (out ? kOut : kEdge);
         }
         if (tie == 0 && cls != kSlow) fix_ties(own, xb, y, hx, lx, hy, ly);
         if (__builtin_expect(cls == kFast, 1)) {
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             const int sx = X >> SH, sy = Y >> SH;
             const uint32_t fx = (uint32_t)X & 31u, fy = (uint32_t)Y & 31u;
             constexpr int kTap = INTERP == kLinear ? 1 : 0;  // taps reach sx + kTap, sy + kTap
-            const bool all_out = fill_ok && (sx < -kTap || sx >= a.src_w || sy < -kTap || sy >= a.src_h);
+            const bool all_out = sx < -kTap || sx >= a.src_w || sy < -kTap || sy >= a.src_h;
             Pixel<T, C> v;
             if (inb[j]) {
                 if constexpr (sizeof(T) == 1) {
@@ -914,7 +913,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         // outside: all four corners beyond the same frame edge (coordinates representable, W sane) -- the border value
         const bool c_rep = c_w && (((chx ^ kHiExp) | (chy ^ kHiExp)) >> 20) == 0;
         auto all4 = [](bool v) { return ((uint32_t)__ballot(v) & 0xFu) == 0xFu; };
-        tile_out = fill_ok && one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > a.src_w) || all4(csy <= -3) || all4(csy > a.src_h));
+        tile_out = one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > a.src_w) || all4(csy <= -3) || all4(csy > a.src_h));
         // Turned footprints.  A row gather's 64 lanes lie on a source line that crosses dy source rows per 64 destination
         // pixels -- a cache line each once dy passes the lines the run would touch anyway -- and pixels sqrt(dx^2 + dy^2) / 64 apart;
         // a 16 x 4 patch of the same 64 pixels crosses a quarter of them.  Measured crossover (A/B over angles and

@@ -8,8 +8,12 @@ and leave /root/reference/vis_homo.py:89-91, bev/homo.py:36 and bev/tool/compo.p
     cv2.warpPerspective(img, H, (w, h)[, dst, flags, borderMode, borderValue])   vis_homo.py:89,91; compo.py:38,46,47
     cv2.findHomography(pts_src, pts_tgt[, method]) -> (H, mask)                  bev/homo.py:36
     cv2.perspectiveTransform(pts (N,1,2), H) -> (N,1,2)                          (OpenCV's name for pts_world_bev, bev/rbox.py:136-151)
-    cv2.resize(img, (w, h))                                                      vis_homo.py:90 (see the note on resize)
     cv2.invert(M) -> (retval, M_inv)                                             the 3x3 step inside warpPerspective
+
+`cv2.resize` (vis_homo.py:90) is deliberately NOT here: a resize routed through the warp kernel (1/32-px positions, constant
+border) is not cv2.resize (11-bit coefficients, replicated edge) and a shim that returns different pixels under cv2's name is
+a trap.  Under `python -m bev_amd.run` the real cv2 keeps its resize; on the fast path the "small" branch needs none
+(bev_amd.warp.warp_perspective_resized folds the resize into the homography).
 
 Pixel work runs on the GPU through libbevwarp.so (no CPU fallback); numpy images go up and come back per call, which is
 what the cv2 call shape implies -- keep frames resident and use bev_amd.warp.warp_perspective / bev_amd.pipeline for
@@ -59,20 +63,6 @@ def perspectiveTransform(src, m):
     flat = pts.reshape(-1, 2).astype(np.float64)
     out = _pts_world_bev(flat, np.asarray(m, dtype=np.float64))
     return out.astype(pts.dtype).reshape(pts.shape)
-
-
-def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
-    """Bilinear / nearest resize THROUGH THE WARP KERNEL with the pixel-centre mapping cv2.resize uses
-    (x_src = (x_dst + 0.5) * w_src / w_dst - 0.5).  Not bit-identical to cv2.resize: the warp quantises sample positions to
-    1/32 px and blends with a constant border, cv2.resize uses 11-bit coefficients and replicates the edge -- interior
-    pixels agree to +-1 LSB, the outermost half pixel differs.  For the reference's "small" branch (vis_homo.py:90-91) prefer
-    bev_amd.warp.warp_perspective_resized, which folds the resize into the homography and never materialises the image."""
-    img = np.asarray(src)
-    h, w = img.shape[:2]
-    if dsize is None or tuple(dsize) == (0, 0):
-        dsize = (int(round(w * fx)), int(round(h * fy)))
-    S = _warp.resize_matrix((w, h), dsize, align_corners=False)
-    return _warp.warpPerspective(img, S, dsize, dst=dst, flags=interpolation)
 
 
 def invert(src, flags=DECOMP_LU):

@@ -1,8 +1,11 @@
 """HIP-graph replay of a per-camera step.
 
-A single warp launch is already cheap to issue (11.5 us per resident 1080p frame back to back, tools/bench_geom.py);
-a tracker step is a dozen small launches and is launch-bound: 160 us eagerly, 78 us replayed.  `GraphedStep` captures
-any function of static device buffers once (torch.cuda.CUDAGraph, i.e. hipGraph) and replays it with one launch."""
+`GraphedStep` captures any function of static device buffers once (torch.cuda.CUDAGraph, i.e. hipGraph) and replays it
+with one launch.  It pays for steps made of MANY small launches.  The per-camera step of this package no longer is one: the
+warp is one launch and the tracker geometry is one launch (bevwarp_tracker_step), and two launches issue eagerly in less
+time than one graph launch costs on this runtime (BENCH_r02.json configs[4]: eager 32.0 us, replay 34.8 us; round 1's
+twelve-launch step was 160 us eager against 78 us replayed).  Use it when a step chains further kernels of the caller's own
+(a detector's pre-processing, say); for the two launches alone call them eagerly -- bench.py reports both."""
 import torch
 
 

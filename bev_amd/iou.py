@@ -34,3 +34,14 @@ def iou_batch_rbox(bb_test, bb_gt, device="cuda"):
     ta = torch.from_numpy(np.ascontiguousarray(bb_test[:, :5], dtype=np.float64)).to(device)
     tb = torch.from_numpy(np.ascontiguousarray(bb_gt[:, :5], dtype=np.float64)).to(device)
     return rbox_iou(ta, tb).cpu().numpy()
+
+
+def iou_any(boxes1, boxes2, device="cuda"):
+    """`d3d.box.box2d_iou(boxes1, boxes2, method="rbox")` call shape (rbox_tracker.py:92): numpy arrays or torch tensors
+    (any device) of [x, y, w, h, yaw] rows in, the (N, M) IoU matrix of the same kind out."""
+    if isinstance(boxes1, torch.Tensor):
+        b2 = boxes2 if isinstance(boxes2, torch.Tensor) else torch.as_tensor(np.asarray(boxes2))
+        dt = boxes1.dtype if boxes1.dtype in _DTYPES else torch.float64
+        dev = boxes1.device if boxes1.is_cuda else torch.device(device)
+        return rbox_iou(boxes1[:, :5].to(dev, dt), b2[:, :5].to(dev, dt)).to(boxes1.device)
+    return iou_batch_rbox(np.asarray(boxes1), np.asarray(boxes2), device=device)

@@ -111,14 +111,31 @@ class FramePipeline:
         self._out_bytes = self.d_out[0].numel() * self.d_out[0].element_size()
         self.n_in = 0
         self.pending = collections.deque()  # slots whose results have not been handed out yet
+        self._closed = False
 
-    def __del__(self):
+    def close(self):
+        """Drain the three private streams, then release the events.  The device / pinned buffers were only ever handed to those
+        streams as raw addresses (torch does not know they are in use there), so they must not be freed before this."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
         try:
+            for st in self._streams:
+                st.synchronize()
             hip = _hip_rt()
             for e in self.ev_up + self.ev_run + self.ev_down:
                 hip.hipEventDestroy(e)
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
 
     def _launch_py(self, slot, stream):
         """The same launch through bev_amd.warp (argument validation; used once per slot at construction)."""
@@ -139,6 +156,9 @@ class FramePipeline:
         return self.h_in[slot].numpy()
 
     def commit(self):
+        if len(self.pending) >= self.depth:  # the slot about to be reused still holds a result nobody has taken
+            raise RuntimeError("FramePipeline: %d frames are in flight and none has been taken with result(); a ring of depth %d "
+                               "holds at most %d undelivered frames" % (len(self.pending), self.depth, self.depth))
         hip = _hip_rt()
         slot = self.n_in % self.depth
         self.n_in += 1

@@ -48,6 +48,18 @@ def rbox_world_bev_device(rbox_src, H, src):
     return out
 
 
+def _check_out_dict(out, n, m, dtype, device, want_img):
+    """A reused result dict goes to the kernel as raw addresses: every tensor must be exactly what the launch writes."""
+    need = {"dets_world": ((n, 5), dtype), "iou": ((n, m), dtype), "candidates": ((n, m), torch.bool)}
+    if want_img:
+        need["dets_img"] = ((n, 2), dtype)
+    for key, (shape, dt) in need.items():
+        t = out.get(key) if isinstance(out, dict) else None
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != shape or t.dtype != dt or t.device != device or not t.is_contiguous():
+            raise ValueError("out[%r] must be a contiguous %s tensor of shape %s on %s (reuse only the dict of a call with the same "
+                             "n, m, dtype and H_img_world)" % (key, dt, shape, device))
+
+
 def tracker_geometry_step(dets_bev, trks_world, H_world_bev, iou_threshold=0.3, H_img_world=None, device="cuda", out=None):
     """dets_bev (n, >=5) detections in BEV pixels, trks_world (m, >=5) predicted tracker boxes in the world (numpy or
     tensors; float64 unless both are float32 tensors).  Returns a dict of device tensors: dets_world (n, 5), iou (n, m),
@@ -59,7 +71,9 @@ def tracker_geometry_step(dets_bev, trks_world, H_world_bev, iou_threshold=0.3, 
         d, t = d.to(torch.float64), t.to(torch.float64)
     d, t = _boxes(d, "dets_bev"), _boxes(t, "trks_world")
     n, m = d.shape[0], t.shape[0]
-    if out is None:
+    if out is not None:
+        _check_out_dict(out, n, m, d.dtype, d.device, H_img_world is not None)
+    else:
         out = {"dets_world": torch.empty((n, 5), dtype=d.dtype, device=d.device), "iou": torch.empty((n, m), dtype=d.dtype, device=d.device),
                "candidates": torch.empty((n, m), dtype=torch.bool, device=d.device)}
         if H_img_world is not None:

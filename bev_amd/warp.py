@@ -36,6 +36,7 @@ def invert_homography(M):
 
 
 _MINV_CACHE_MAX = 256
+_MINV_PINNED_MAX = 4096
 _minv_cache = collections.OrderedDict()  # (matrix bytes, device, inverse_given) -> device tensor, least recently used first
 _minv_pinned = {}                        # entries whose address a hipGraph capture has seen: never evicted
 
@@ -46,14 +47,18 @@ def device_inverse(M, device, inverse_given=False):
     Lifetime rules (launches only ever receive the tensor's raw address): every use records the current stream on the
     tensor, so an evicted entry's memory is not handed out again before the launches that read it have run; an entry
     that is looked up while the current stream is being captured into a graph is pinned for the life of the process
-    (the graph replays its address), and a cache MISS during capture raises -- upload the matrices before capturing
+    (the graph replays its address; 72 bytes per matrix, at most _MINV_PINNED_MAX entries -- re-capturing with ever new
+    matrices beyond that raises: pass `M_inv_device`), and a cache MISS during capture raises -- upload the matrices before capturing
     (or pass `M_inv_device`, which the caller owns)."""
     if isinstance(M, torch.Tensor) and M.is_cuda and inverse_given:
         return M.to(torch.float64).reshape(-1, 3, 3).contiguous()
     device = torch.device(device)
     Mh = np.ascontiguousarray(M.detach().cpu().numpy() if isinstance(M, torch.Tensor) else M, dtype=np.float64).reshape(-1, 3, 3)
     key = (Mh.tobytes(), str(device), bool(inverse_given))
-    capturing = device.type == "cuda" and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    capturing = False
+    if device.type == "cuda" and torch.cuda.is_available():
+        with torch.cuda.device(device):  # the capture state of THIS device's current stream, not of the default device's
+            capturing = torch.cuda.is_current_stream_capturing()
     hit = _minv_pinned.get(key)
     if hit is not None:
         return hit
@@ -70,10 +75,23 @@ def device_inverse(M, device, inverse_given=False):
     else:
         _minv_cache.move_to_end(key)
     if capturing:
+        if len(_minv_pinned) >= _MINV_PINNED_MAX:
+            raise RuntimeError("device_inverse: %d homography sets are already pinned by graph captures; pass M_inv_device (a tensor the "
+                               "caller owns) when capturing graphs with ever new matrices" % _MINV_PINNED_MAX)
         _minv_pinned[key] = _minv_cache.pop(key)
     elif hit.is_cuda:
         hit.record_stream(torch.cuda.current_stream(hit.device))
     return hit
+
+
+try:  # the current stream's raw hipStream_t without building a torch.cuda.Stream object (~0.2 us instead of ~1.5)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover - older / CPU-only builds
+    def _raw_stream(dev_index):
+        return torch.cuda.current_stream(dev_index).cuda_stream
+
+_PLANS_MAX = 1024
+_plans = {}  # validated launches by (addresses, shapes, strides, dtypes, dsize, flags) -> (entry point, bound arguments, device index)
 
 
 def _check_minv(M_inv_device, device, B):
@@ -111,6 +129,28 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     flags    INTER_LINEAR (default) or INTER_NEAREST, optionally | WARP_INVERSE_MAP.
     out      optional preallocated result; M_inv_device optional (n, 3, 3) f64 CUDA tensor to skip the cache.
     Returns a tensor shaped like src with (height, width) replaced.  Asynchronous on the current stream."""
+    if out is not None and M_inv_device is not None and border_value is None:
+        # Steady-state call of a camera loop: same buffers, same geometry as a call that has already been validated.  The
+        # whole Python layer is then one dictionary lookup and the C call with its argument tuple bound (a single 720p -> 512^2
+        # frame is a 10-us kernel: the general path below costs more host time than that).
+        try:
+            key = (src.data_ptr(), out.data_ptr(), M_inv_device.data_ptr(), src.shape, src.stride(), out.shape, out.stride(), M_inv_device.shape,
+                   M_inv_device.stride(), src.dtype, out.dtype, dsize[0], dsize[1], flags)
+            plan = _plans.get(key)
+        except (AttributeError, TypeError, IndexError):
+            plan = None
+        if plan is not None:
+            fn, args, dev_index = plan
+            if torch.cuda.current_device() == dev_index:
+                st = fn(*args, _raw_stream(dev_index))
+            else:
+                with torch.cuda.device(dev_index):
+                    st = fn(*args, _raw_stream(dev_index))
+            if st:
+                _lib.check(st)
+            return out
+    else:
+        key = None
     if not isinstance(src, torch.Tensor) or not src.is_cuda:
         raise ValueError("warp_perspective needs a CUDA (HIP) tensor; use warpPerspective for numpy images")
     if src.dtype not in _DTYPES:
@@ -143,13 +183,16 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
             raise ValueError("out must be a contiguous-row channels-last tensor")
     bv = _border(border_value, C)
     stream = torch.cuda.current_stream(s4.device).cuda_stream
+    args = (s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C, s4.stride(0) * esz, s4.stride(1) * esz, d4.stride(0) * esz, d4.stride(1) * esz,
+            M_inv_device.data_ptr(), n_m, _DTYPES[s4.dtype], interp, None if bv is None else bv.ctypes.data_as(ctypes.c_void_p))
+    fn = _lib.load().bevwarp_warp
     with torch.cuda.device(s4.device):
-        st = _lib.load().bevwarp_warp(
-            s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C,
-            s4.stride(0) * esz, s4.stride(1) * esz, d4.stride(0) * esz, d4.stride(1) * esz,
-            M_inv_device.data_ptr(), n_m, _DTYPES[s4.dtype], interp,
-            None if bv is None else bv.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(stream))
+        st = fn(*args, ctypes.c_void_p(stream))
     _lib.check(st)
+    if key is not None and s4 is src:  # validated and launched: the next call with these very buffers skips the checks
+        if len(_plans) >= _PLANS_MAX:
+            _plans.clear()
+        _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device())
     if out is not None:
         return out
     if len(shape) == 2:

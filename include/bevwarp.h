@@ -77,7 +77,11 @@ int bevwarp_invert_homography(const double *M_fwd /*HOST*/, double *M_inv /*HOST
  * dst[b] = warpPerspective(src[b], M[b], (dst_w, dst_h)) for b in [0, batch), BORDER_CONSTANT.
  *
  *   src, dst       device; `channels` interleaved values of `dtype` (BEVWARP_U8 | BEVWARP_F32) per pixel.
- *                  src and dst must not overlap.
+ *                  src and dst must not overlap: the call returns BEVWARP_ERR_BAD_ARG when the byte ranges
+ *                  [src, last byte of frame batch-1] and [dst, last byte of frame batch-1] intersect (an
+ *                  in-place warp would read taps other workgroups have already overwritten).
+ *                  "each tap outside replaced by the border value": a pixel whose four taps are ALL outside
+ *                  is the border value itself (float32 too), as in OpenCV's remapBilinear.
  *   *_frame_stride bytes between consecutive frames; *_row_stride bytes between rows (>= row bytes).
  *   M_inv          device; INVERSE (dst px -> src px) matrices, float64, row-major;
  *                  m_count == batch (one per frame) or 1 (shared by all frames).
@@ -100,6 +104,7 @@ int bevwarp_warp(const void *src, void *dst, int batch, int src_h, int src_w, in
  *   dst             device float32; dst_plane_stride bytes between channel planes, dst_row_stride between rows,
  *                   dst_frame_stride between frames (all multiples of 4; multiples of 16 enable the wide stores).
  *   scale, bias     HOST, `channels` doubles each (converted to float32); NULL = 1 and 0.
+ * Overlap of src and dst: as for bevwarp_warp (BEVWARP_ERR_BAD_ARG).
  */
 int bevwarp_warp_planar(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,

@@ -104,4 +104,7 @@ def warp_perspective(src, M, dsize, interp=LINEAR, m_is_inverse=False, border_va
         out = ((tap(sx, sy) * w00[..., None] + tap(sx + 1, sy) * w01[..., None]) + tap(sx, sy + 1) * w10[..., None]) + \
             tap(sx + 1, sy + 1) * w11[..., None]
         out = out.astype(np.float32)
+    if interp != NEAREST:  # remapBilinear's "fully outside" path stores the border value itself, not a blend of four of them
+        all_out = (sx >= w) | (sx + 1 < 0) | (sy >= h) | (sy + 1 < 0)
+        out = np.where(all_out[..., None], cval[None, None, :], out).astype(s3.dtype)
     return out[:, :, 0] if squeeze else out

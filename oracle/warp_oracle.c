@@ -22,7 +22,11 @@
  * INTER_REMAP_COEF_BITS = 15), the classic scalar code path -- NOT the IPP or
  * OpenCL dispatches and not the OpenCV 5 rewrite, which may differ in last
  * bits.  "Bit-exact" anywhere in this repository means: equal to THIS
- * algorithm, not to whatever cv2 build a user has installed.  It is pinned
+ * algorithm, not to whatever cv2 build a user has installed.  Every rule here
+ * -- including remapBilinear's three BORDER_CONSTANT paths (fully inside,
+ * fully outside = cval stored directly, straddling = per-tap substitution) --
+ * is restated from memory of that source file; none could be checked against
+ * OpenCV in this image.  It is pinned
  * by the analytic known-answer tests in tests/test_oracle_warp.py and by an
  * independent numpy twin (oracle/warp_numpy.py).  pts_world_bev IS pinned:
  * tests/golden/reference_vectors.json holds outputs of the reference itself.
@@ -210,9 +214,22 @@ static void warp_rows(const unsigned char *src, int sh, int sw, int64_t sstep, u
                     memcpy(D, cval_f, (size_t)cn * 4);
                 continue;
             }
-            /* remapBilinear, BORDER_CONSTANT: each of the 4 taps individually replaced by
-             * the border value when it falls outside (the three code paths of the original --
-             * fully inside, fully outside, straddling -- all reduce to this). */
+            /* remapBilinear, BORDER_CONSTANT, three code paths of the original:
+             *   fully inside   -> the plain 4-tap sum;
+             *   fully outside  -> `sx >= ssize.width || sx + 1 < 0 || sy >= ssize.height || sy + 1 < 0`
+             *                     stores cval[k] DIRECTLY (no blend: for float32 a 4-term sum of
+             *                     cval * w would differ from cval by an ulp for most border values);
+             *   straddling     -> each of the 4 taps individually replaced by the border value.
+             * The first and third coincide; the second is handled here.  (Restated from memory of
+             * imgwarp.cpp like the rest of this file: parity unpinned.) */
+            if (drow && (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0)) {
+                unsigned char *D = drow + (int64_t)x * cn * esz;
+                if (dtype == ORACLE_U8)
+                    memcpy(D, cval_u8, (size_t)cn);
+                else
+                    memcpy(D, cval_f, (size_t)cn * 4);
+                continue;
+            }
             int in00 = sx >= 0 && sy >= 0 && sx < sw && sy < sh;
             int in01 = sx + 1 >= 0 && sy >= 0 && sx + 1 < sw && sy < sh;
             int in10 = sx >= 0 && sy + 1 >= 0 && sx < sw && sy + 1 < sh;

@@ -50,7 +50,8 @@ def test_strerror_and_argument_validation_without_a_device(lib):
         assert len(lib.bevwarp_strerror(code)) > 4
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
     warp = lib.bevwarp_warp
-    ok_args = [one, one, 1, 8, 8, 8, 8, 3, 192, 24, 192, 24, one, 1, _lib.U8, 1, None, None]
+    far = ctypes.c_void_p(1 << 20)  # a destination that does not overlap the source
+    ok_args = [one, far, 1, 8, 8, 8, 8, 3, 192, 24, 192, 24, one, 1, _lib.U8, 1, None, None]
 
     def call(**patch):
         a = list(ok_args)
@@ -67,6 +68,15 @@ def test_strerror_and_argument_validation_without_a_device(lib):
     assert call(a13=2) == -1            # 2 matrices for a batch of 1
     assert call(a4=40000, a9=120000, a8=960000) == -3  # source wider than 32767
     assert call(a2=0) == 0              # empty batch is a no-op
+    # src and dst must not overlap (include/bevwarp.h): in place, partially, and batch-wise through the frame strides
+    assert call(a1=one) == -1
+    assert call(a1=ctypes.c_void_p(16 + 191)) == -1          # the last source byte
+    assert call(a1=ctypes.c_void_p(16 + 192), a16=ctypes.cast((ctypes.c_double * 3)(0.0, float("nan"), 0.0), ctypes.c_void_p)) == -4  # adjacent is fine (fails later, on the border)
+    assert call(a2=4, a1=ctypes.c_void_p(16 + 3 * 192 + 100)) == -1   # inside frame 3 of a 4-frame source
+    assert call(a2=4, a0=ctypes.c_void_p((1 << 20) + 3 * 192 + 191)) == -1  # source starting on the last byte of destination frame 3
+    planar = lib.bevwarp_warp_planar
+    pargs = [one, ctypes.c_void_p(16 + 100), 1, 8, 8, 8, 8, 3, 192, 24, 768, 256, 32, one, 1, _lib.U8, 1, None, None, None, None]
+    assert planar(*pargs) == -1
     bad_border = (ctypes.c_double * 3)(0.0, float("nan"), 0.0)
     assert call(a16=ctypes.cast(bad_border, ctypes.c_void_p)) == -4
     H = (ctypes.c_double * 9)(*[float("inf")] * 9)

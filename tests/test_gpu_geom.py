@@ -282,3 +282,55 @@ def test_frame_pipeline_matches_resident_path():
     pipe = FramePipeline((sh, sw), 3, M, (dw, dh), dtype=torch.float32)
     for g, f in zip(pipe.run(f32), f32):
         np.testing.assert_array_equal(g, co.warp_perspective(f, M, (dw, dh), 1))
+
+
+def test_frame_pipeline_refuses_to_overwrite_an_undelivered_result():
+    """A ring of depth d holds d undelivered frames: one more commit would store into a slot whose result nobody has taken."""
+    from bev_amd.pipeline import FramePipeline
+    from tests import workloads as wl
+    sw, sh, dw, dh = 320, 180, 128, 96
+    M = wl.synth_brno_H(sw, sh, dw, dh)
+    frames = [wl.frame(80 + i, sh, sw, np.uint8) for i in range(4)]
+    with FramePipeline((sh, sw), 3, M, (dw, dh), depth=3) as pipe:
+        for f in frames[:3]:
+            pipe.submit(f)
+        with pytest.raises(RuntimeError):
+            pipe.submit(frames[3])
+        assert pipe.ready() == 3
+        got = [pipe.result().copy() for _ in range(3)]  # the three delivered frames are intact
+        for g, f in zip(got, frames[:3]):
+            np.testing.assert_array_equal(g, co.warp_perspective(f, M, (dw, dh), 1))
+        pipe.submit(frames[3])
+        np.testing.assert_array_equal(pipe.result(), co.warp_perspective(frames[3], M, (dw, dh), 1))
+    pipe.close()  # idempotent
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_warp_composite_every_channel_count(c):
+    """bevwarp_warp_composite advertises 1-4 channels and bit-identity with three warps + the blend: guarded taps (a small
+    odd-sized foreground / mask, maps that leave the frames) and unguarded ones (interior), every C."""
+    from bev_amd.compo import composite_bev_img, composite_reg_img
+    from bev_amd.homo import homo_from_KRt
+    from bev_amd.warp import warp_perspective
+    from tests import workloads as wl
+    K = np.array([[400.0, 0, 159.0], [0, 395.0, 88.5], [0, 0, 1.0]])
+    cth, sth = np.cos(0.8), np.sin(0.8)
+    RT = np.array([[1, 0, 0, 0.0], [0, cth, -sth, 2.0], [0, sth, cth, 14.0], [0, 0, 0, 1.0]])
+    H_world2bev = np.array([[0.0, 14.0, 250.0], [-14.0, 0.0, 60.0], [0.0, 0.0, 1.0]])
+    H_img2world_fix = np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)) @ np.array([[1, 0, 2.0], [0, 1, -1.0], [0, 0, 1]])
+    bg = wl.frame(20, 360, 640, np.uint8, c)
+    for (fh, fw, dw, dh) in ((177, 319, 301, 517), (360, 640, 512, 96)):
+        fg, mask = wl.frame(21, fh, fw, np.uint8, c), wl.frame(22, fh, fw, np.uint8, c)
+        Ks = np.diag([fw / 320.0, fh / 178.0, 1.0]) @ K
+        got, Hcam = composite_bev_img(torch.from_numpy(bg).cuda(), fg, mask, H_world2bev, H_img2world_fix, Ks, RT, dw, dh)
+        Hb, Hc = H_world2bev.dot(H_img2world_fix), H_world2bev.dot(np.linalg.inv(Hcam))
+        cu = [torch.from_numpy(x).cuda() for x in (bg, fg, mask)]
+        three = composite_reg_img(warp_perspective(cu[0], Hb, (dw, dh)), warp_perspective(cu[1], Hc, (dw, dh)), warp_perspective(cu[2], Hc, (dw, dh)))
+        assert got.shape == (dh, dw, c) and torch.equal(three.reshape(dh, dw, c), got)
+        fb, ff, fm = (co.warp_perspective(x, H, (dw, dh)).astype(np.float64).reshape(dh, dw, c) for x, H in ((bg, Hb), (fg, Hc), (mask, Hc)))
+        exp = np.minimum((ff * (fm / 255) + fb * (1 - fm / 255)).round(), 255).astype(np.uint8)
+        np.testing.assert_array_equal(got.cpu().numpy(), exp)
+        assert 0.02 < (fm > 0).mean() < 1.0  # the camera footprint really is cut by the frame's edge and not empty
+    if c != 3:
+        with pytest.raises(ValueError):
+            composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, Ks, RT, dw, dh, bw_mode=True)

@@ -46,12 +46,33 @@ def test_channels_all_row_classes(W, c, dtype, interp):
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("interp", [0, 1])
 def test_border_values(W, dtype, interp):
-    """Non-zero border: OUT rows are filled for uint8 / nearest; float bilinear blends four border taps per pixel."""
+    """Non-zero border: pixels whose four taps are all outside ARE the border value (float bilinear too: the reference's
+    "fully outside" path stores cval directly), so OUT rows / tiles are filled for every format; straddling pixels substitute
+    the border tap by tap."""
     M = wl.synth_brno_H(640, 360, 512, 64)
     src = wl.frame(6, 360, 640, dtype)
     bv = [7, 200, 33] if dtype == np.uint8 else [0.3, 0.55, 0.7]
     both(W, src, M, (512, 64), interp, border_value=bv)
     both(W, src, M, (512, 64), interp, border_value=bv[0])
+
+
+def test_float_border_far_outside_is_exact(W):
+    """f32, border 0.3, a sub-pixel shift far outside the frame: every pixel == np.float32(0.3) (outside TILES, OUT blocks of
+    edge tiles and the guarded sampler all store the value itself), and a frame the border cuts through matches the oracle."""
+    rng = np.random.default_rng(3)
+    src = rng.random((90, 110, 3), dtype=np.float32)
+    bv = [0.3, 0.7, 1.0 / 3.0]
+    M = np.array([[1, 0, -400.0 - 13 / 32], [0, 1, -250.0 - 7 / 32], [0, 0, 1.0]])
+    out = run_gpu(W, src, M, (300, 70), 1, border_value=bv)
+    for k in range(3):
+        assert (out[..., k] == np.float32(bv[k])).all()
+    for shift in ((-60.0 - 13 / 32, -20.0 - 7 / 32), (95.0 + 5 / 32, 70.0 + 9 / 32), (-100.0 - 1 / 32, 0.25)):
+        M = np.array([[1, 0, shift[0]], [0, 1, shift[1]], [0, 0, 1.0]])
+        both(W, src, M, (300, 70), 1, border_value=bv)
+        both(W, src[:, :, :1].copy(), M, (300, 70), 1, border_value=bv[0])
+    # perspective: W changes sign inside the destination (SLOW rows run the guarded sampler for every pixel)
+    Mp = np.array([[1.0, 0.02, -20.0], [0.01, 1.0, -8.0], [0.004, 0.0005, -0.5]])
+    both(W, src, Mp, (300, 70), 1, border_value=bv)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])

@@ -111,6 +111,32 @@ def test_out_of_bounds_taps_blend_with_zero_and_border_value():
     assert out[0, 0, 0] == np.float32(0.75 * 0.75) and out[1, 1, 1] == 1.0
 
 
+def test_float_pixels_fully_outside_are_the_border_value_itself():
+    """remapBilinear's "fully outside" path (sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0) stores cval[k] directly: a
+    float32 pixel whose four taps are all outside is EXACTLY the border value, not cval*w0 + cval*w1 + cval*w2 + cval*w3
+    (which is an ulp off for most values and sub-pixel positions).  Partial overlap keeps per-tap substitution."""
+    rng = np.random.default_rng(3)
+    src = rng.random((9, 11, 3), dtype=np.float32)
+    bv = [0.3, 0.7, 1.0 / 3.0]
+    # a sub-pixel shift far outside the frame: every destination pixel samples beyond the right / bottom edge
+    M = np.array([[1, 0, -40.0 - 13 / 32], [0, 1, -25.0 - 7 / 32], [0, 0, 1.0]])
+    for fn in (co.warp_perspective, wn.warp_perspective):
+        out = fn(src, M, (16, 12), co.LINEAR, border_value=bv)
+        for k in range(3):
+            assert (out[..., k] == np.float32(bv[k])).all(), (fn.__module__, k)
+    # the 4-term sum the old restatement computed is NOT the border value for this weight set (what the rule is about)
+    w = [np.float32((1 - 7 / 32) * (1 - 13 / 32)), np.float32((1 - 7 / 32) * (13 / 32)), np.float32((7 / 32) * (1 - 13 / 32)), np.float32((7 / 32) * (13 / 32))]
+    c = np.float32(0.3)
+    assert ((c * w[0] + c * w[1]) + c * w[2]) + c * w[3] != c
+    # partial overlap: taps substituted one by one (left tap column outside, right inside)
+    M = np.array([[1, 0, 1.0 - 8 / 32], [0, 1, 0], [0, 0, 1.0]])  # dst x samples src x - 0.75
+    one = np.ones((3, 4, 1), np.float32)
+    out = co.warp_perspective(one, M, (2, 1), co.LINEAR, border_value=0.3)
+    exp0 = (np.float32(0.3) * np.float32(0.75) + np.float32(1.0) * np.float32(0.25)) + np.float32(0) + np.float32(0)
+    assert out[0, 0, 0] == np.float32(exp0)
+    np.testing.assert_array_equal(out, wn.warp_perspective(one, M, (2, 1), co.LINEAR, border_value=0.3))
+
+
 def test_bilinear_table_matches_closed_form_for_all_bytes():
     """BilinearTab_i as OpenCV builds it: (32-fy)(32-fx)*32 ... except {32767,0,0,1} at (0,0), which
     produces the same byte as {32768,0,0,0} for every input."""

@@ -62,3 +62,38 @@ def test_matrix_cache_is_a_bounded_lru_that_keeps_recent_entries(monkeypatch):
     again = warp.device_inverse(mats[1], "cpu")
     np.testing.assert_allclose(again.numpy()[0], np.linalg.inv(mats[1]), rtol=1e-15)
     warp._minv_cache.clear()
+
+
+def test_tracker_out_dict_is_validated_before_its_addresses_reach_the_kernel():
+    from bev_amd import tracker_geom as tg
+    cpu = torch.device("cpu")
+
+    def mk(n, m, dt=torch.float64, img=True):
+        d = {"dets_world": torch.empty((n, 5), dtype=dt), "iou": torch.empty((n, m), dtype=dt), "candidates": torch.empty((n, m), dtype=torch.bool)}
+        if img:
+            d["dets_img"] = torch.empty((n, 2), dtype=dt)
+        return d
+
+    tg._check_out_dict(mk(4, 6), 4, 6, torch.float64, cpu, True)
+    tg._check_out_dict(mk(4, 6, img=False), 4, 6, torch.float64, cpu, False)
+    for bad in (mk(4, 5), mk(3, 6), mk(4, 6, torch.float32), mk(4, 6, img=False), None, {"dets_world": np.zeros((4, 5))}):
+        with pytest.raises(ValueError):  # another n / m, another dtype, no dets_img although H_img_world is given, not a dict of tensors
+            tg._check_out_dict(bad, 4, 6, torch.float64, cpu, True)
+    d = mk(4, 6)
+    d["iou"] = torch.empty((6, 4), dtype=torch.float64).t()  # right shape, not contiguous
+    with pytest.raises(ValueError):
+        tg._check_out_dict(d, 4, 6, torch.float64, cpu, True)
+    d = mk(4, 6)
+    d["candidates"] = torch.empty((4, 6), dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        tg._check_out_dict(d, 4, 6, torch.float64, cpu, True)
+    with pytest.raises(ValueError):
+        tg._check_out_dict(mk(4, 6), 4, 6, torch.float64, torch.device("cuda", 0), True)
+
+
+def test_bw_mode_needs_three_channels():
+    from bev_amd import compo
+    with pytest.raises(ValueError):
+        compo.gray_bgr(torch.zeros((4, 4, 1), dtype=torch.uint8))
+    g = compo.gray_bgr(torch.tensor([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], dtype=torch.uint8))
+    assert g[0, :, 0].tolist() == [29, 150, 76, (1868 * 10 + 9617 * 20 + 4899 * 30 + 8192) >> 14] and (g[..., 0] == g[..., 2]).all()
