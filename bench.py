@@ -20,6 +20,14 @@ ONE JSON line (rank 0).  At N = 1 it also carries, measured in the same run:
              cv2 when this box happens to have it), configs[2] (1e7 points, f32 / f64), configs[3] (the per-GPU shard,
              uint8 and float32), configs[4] (1080p -> 1024^2 uint8 warp + the 512 x 512 tracker launch, eager and replayed
              from a hipGraph), and the PCIe-inclusive frame pipeline
+`roofline.measured_ceiling_gbs` = what a pure streaming kernel with the headline's byte mix (its algorithmic source bytes
+read with plain 16-byte loads, its destination bytes written with non-temporal 16-byte stores -- the warp's access kinds)
+reaches in THIS process on THIS box, on the headline's own buffers, just before the headline runs (tools/streamprobe.hip;
+`measured_ceiling_nt_nt_gbs`: non-temporal loads as well, which gathers cannot use); `frac_of_measured` = achieved / that;
+`sclk_mhz` = the shader clock the chip held inside the warp kernel (s_memtime / s_memrealtime stamps of the diagnostic
+build csrc/variants/clock.so, the method of tools/clock.py) and inside the probe.  u8 variants also carry `roofline_valu`
+(vector-ALU instructions per 256-px wave-row, their issue time, VALU busy fraction) from the committed SQ counter pass, and
+`bound` says which of the two the counters name.
 `roofline.achieved` = algorithmic bytes per launch / mean launch duration from HIP events on the launch stream; algorithmic
 bytes = every destination byte once + every distinct in-bounds source pixel touched by any tap once (exact footprint,
 counted on the GPU by bevwarp_footprint).  `roofline.traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
@@ -60,6 +68,7 @@ def parse():
     p.add_argument("--homography", choices=["keystone", "brno"], default="keystone")
     p.add_argument("--sets", type=int, default=0, help="distinct buffer sets to rotate (0 = enough for > 1 GB)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-probe", action="store_true", help="skip the same-process streaming-ceiling probe and the in-kernel clock reading")
     p.add_argument("--no-variants", action="store_true", help="skip the extra measurements of configs[1] (N = 1)")
     p.add_argument("--no-configs", action="store_true", help="skip the configs block (N = 1)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
@@ -149,10 +158,11 @@ def cpu_baseline(frames_np, Ms, dsize, interp, gpu_out, budget_s):
     return res
 
 
-def load_traffic(dtype, interp, args):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None when the workload is not the one
-    that was profiled (configs[1] at its default shape) or the kernel source has changed since."""
-    if (args.batch, tuple(args.src), tuple(args.dst), args.homography) != (32, (1920, 1080), (1024, 1024), "keystone"):
+def load_profile(dtype, interp, homography, args):
+    """The committed rocprofv3 --pmc record of this workload (profiles/pmc_traffic.json: HBM bytes per launch, SQ counters), or
+    None when the workload is not one that was profiled (configs[1] at its default shape, keystone or brno) or the kernel
+    source has changed since."""
+    if (args.batch, tuple(args.src), tuple(args.dst)) != (32, (1920, 1080), (1024, 1024)):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -161,7 +171,93 @@ def load_traffic(dtype, interp, args):
         return None
     if d.get("kernel_source_sha") != kernel_source_sha():
         return None
-    return d.get("%s_%s" % (dtype, interp), {}).get("hbm_bytes_per_launch")
+    return d.get("%s_%s%s" % (dtype, interp, "" if homography == "keystone" else "_" + homography))
+
+
+def load_traffic(dtype, interp, homography, args):
+    rec = load_profile(dtype, interp, homography, args)
+    return None if rec is None else rec.get("hbm_bytes_per_launch")
+
+
+_probe_lib = None
+
+
+def probe_lib():
+    """tools/libstreamprobe.so (built by __graft_entry__.build(); measurement aid, not part of libbevwarp.so)."""
+    global _probe_lib
+    if _probe_lib is None:
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libstreamprobe.so"))
+        lib.probe_stream.restype = ctypes.c_int
+        lib.probe_stream.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p]
+        _probe_lib = lib
+    return _probe_lib
+
+
+def measured_ceiling(w):
+    """Same process, same buffers, same byte mix as workload `w`: read its algorithmic source bytes, write its destination
+    bytes, nothing else.  Returns GB/s by access kind (median over launches, best grid) and the clock the probe ran at."""
+    import ctypes
+    try:
+        lib = probe_lib()
+    except OSError as e:
+        return {"error": "tools/libstreamprobe.so not built: %s" % e}
+    read_b = min(w.footprint_px * w.C * w.esz, w.srcs[0].numel() * w.esz) // 16 * 16
+    write_b = w.dsts[0].numel() * w.dsts[0].element_size() // 16 * 16
+    clk = torch.zeros(3, dtype=torch.int64, device=w.srcs[0].device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {"read_bytes": read_b, "write_bytes": write_b}
+    for label, ntl in (("plain_loads_nt_stores", 0), ("nt_loads_nt_stores", 1)):
+        best = None
+        for grid in (4096, 8192):
+            k = [0]
+
+            def launch():
+                i = k[0] % w.nsets
+                k[0] += 1
+                rc = lib.probe_stream(w.srcs[i].data_ptr(), read_b, w.dsts[i].data_ptr(), write_b, ntl, 1, grid, stream, clk.data_ptr())
+                if rc:
+                    raise RuntimeError("probe_stream failed: %d" % rc)
+
+            t = float(np.median(event_times(launch, 20, 4)))
+            best = t if best is None else min(best, t)
+        out[label] = {"us": round(best * 1e6, 1), "gbs": round((read_b + write_b) / best / 1e9, 1)}
+    c = clk.cpu().numpy()
+    out["sclk_mhz_probe"] = round(100.0 * float(c[0]) / max(float(c[1]), 1.0), 0)
+    return out
+
+
+def kernel_clock(w, launches=300):
+    """Shader clock held INSIDE the warp kernel: the diagnostic build of the same sources (csrc/variants/clock.so, -DBEVWARP_CLOCK:
+    one s_memtime / s_memrealtime stamp pair per workgroup) launched back to back on the headline's buffers."""
+    import ctypes
+    path = os.path.join(ROOT, "bev_amd", "csrc", "variants", "clock.so")
+    if not os.path.exists(path):
+        return None
+    from bev_amd import _lib
+    lib = ctypes.CDLL(path)
+    fn = lib.bevwarp_warp
+    fn.restype, fn.argtypes = _lib.SYMBOLS["bevwarp_warp"]
+    dbg = lib.bevwarp_debug_clock
+    dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
+    esz, stream = w.esz, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out4 = (ctypes.c_ulonglong * 4)()
+
+    def run(n):
+        for i in range(n):
+            s, d = w.srcs[i % w.nsets], w.dsts[i % w.nsets]
+            rc = fn(s.data_ptr(), d.data_ptr(), w.B, w.sh, w.sw, w.dh, w.dw, w.C, s.stride(0) * esz, s.stride(1) * esz, d.stride(0) * esz, d.stride(1) * esz,
+                    w.minv.data_ptr(), w.minv.shape[0], 0 if esz == 1 else 1, w.interp, None, stream)
+            if rc:
+                raise RuntimeError("clock build: bevwarp_warp returned %d" % rc)
+        torch.cuda.synchronize()
+
+    run(launches)          # reach the sustained state
+    assert dbg(out4, 1) == 0
+    run(50)
+    assert dbg(out4, 0) == 0
+    return round(100.0 * out4[0] / max(out4[1], 1), 0) if out4[2] else None
 
 
 def event_times(fn, n, warm):
@@ -234,34 +330,64 @@ class Workload:
     def run(self, steps, warmup, barrier):
         for i in range(warmup):
             self.step(i)
-        barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()  # torch.cuda.synchronize + process-group barrier + synchronize: every rank starts its K steps together
         t0 = time.perf_counter()
         for i in range(steps):
             ev[i][0].record()
             self.step(i)
             ev[i][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # this rank's K steps; the job's time is the MAX over ranks (taken by the caller)
         barrier()
-        elapsed = time.perf_counter() - t0
         launch_ms = np.array([a.elapsed_time(b) for a, b in ev])
         return elapsed, launch_ms
 
-    def roofline(self, launch_ms):
+    def roofline(self, launch_ms, ceiling=None, sclk_mhz=None):
         kernel_s = float(launch_ms.mean()) / 1e3
         achieved = self.algo_bytes / kernel_s / 1e9
-        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None if (self.planar or self.homography != "keystone") else load_traffic(self.dtype, self.interp_name, self.args),
-                "kernel": "warp_rows<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
-                "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
-                "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
-                "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
+        rec = None if self.planar else load_profile(self.dtype, self.interp_name, self.homography, self.args)
+        r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "traffic": None if rec is None else rec.get("hbm_bytes_per_launch"),
+             "kernel": "warp_rows<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
+             "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
+             "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
+             "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
+        if ceiling is not None and "plain_loads_nt_stores" in ceiling:
+            r["measured_ceiling_gbs"] = ceiling["plain_loads_nt_stores"]["gbs"]
+            r["measured_ceiling_nt_nt_gbs"] = ceiling["nt_loads_nt_stores"]["gbs"]
+            r["frac_of_measured"] = round(achieved / ceiling["plain_loads_nt_stores"]["gbs"], 4)
+            r["measured_ceiling"] = ceiling
+        elif ceiling is not None:
+            r["measured_ceiling"] = ceiling
+        if sclk_mhz is not None:
+            r["sclk_mhz"] = sclk_mhz
+        sq = None if rec is None else rec.get("sq")
+        if sq and sq.get("SQ_INSTS_VALU"):
+            # vector-ALU accounting from the committed SQ pass (per launch): instructions per 256-px (u8) / 128-px (f32) wave-row,
+            # the time they take to ISSUE on 1024 SIMDs at 4 cycles each, and the share of the kernel's duration a SIMD's VALU is busy
+            clk = (sclk_mhz or rec.get("sclk_mhz") or 2400.0) * 1e6
+            wave_rows = self.B * self.dh * ((self.dw + (255 if self.esz == 1 else 127)) // (256 if self.esz == 1 else 128))
+            issue_s = sq["SQ_INSTS_VALU"] * 4.0 / 1024.0 / clk
+            prof_s = rec.get("kernel_avg_ns_profiled", kernel_s * 1e9) * 1e-9
+            busy = sq.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * prof_s * clk)
+            r["roofline_valu"] = {"insts_per_launch": sq["SQ_INSTS_VALU"], "insts_per_wave_row": round(sq["SQ_INSTS_VALU"] / wave_rows, 1),
+                                  "issue_us": round(issue_s * 1e6, 1), "busy_frac": round(busy, 3), "clock_mhz_used": round(clk / 1e6, 0),
+                                  "kernel_us_profiled": round(prof_s * 1e6, 2), "source": rec.get("source")}
+            hbm_share = (rec.get("hbm_bytes_per_launch") or self.algo_bytes) / prof_s / 1e9 / (r.get("measured_ceiling_gbs") or 5500.0)
+            if busy > hbm_share:  # the VALU is busier than the memory system is full: name it
+                r["bound"] = "valu-issue"
+            r["hbm_share_of_streaming_ceiling"] = round(hbm_share, 3)
+        return r
 
 
-def variant_line(w, steps, warmup, barrier, label=None):
+def variant_line(w, steps, warmup, barrier, label=None, probe=False):
+    ceiling = measured_ceiling(w) if probe else None
     el, lm = w.run(steps, warmup, barrier)
     return {"dtype": label or w.dtype, "interp": w.interp_name, "homography": w.homography,
-            "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4), "roofline": w.roofline(lm)}
+            "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4),
+            "roofline": w.roofline(lm, ceiling=ceiling)}
 
 
 # ---- the other configs of BASELINE.json, bounded (N = 1) -------------------------------------------------------------------
@@ -479,8 +605,19 @@ def main():
 
     big = args.config == 3
     main_wl = Workload(args, args.dtype, args.interp, rank, dev, device_frames=big and args.no_cpu_baseline)
-    elapsed, launch_ms = main_wl.run(args.steps, args.warmup, shard.barrier)
-    elapsed = shard.max_over_ranks(elapsed)
+    ceiling = measured_ceiling(main_wl) if (rank == 0 and not args.no_probe) else None  # same process, same buffers, before the headline
+    elapsed_local, launch_ms = main_wl.run(args.steps, args.warmup, shard.barrier)
+    elapsed = shard.max_over_ranks(elapsed_local)
+    kernel_ms_max = shard.max_over_ranks(float(launch_ms.mean()))  # slowest rank's mean launch duration (HIP events)
+    kernel_ms_min = -shard.max_over_ranks(-float(launch_ms.mean()))
+    sclk = None
+    if rank == 0 and not args.no_probe:
+        try:
+            sclk = kernel_clock(main_wl)
+        except Exception as e:  # a diagnostic must not lose the headline
+            sclk = None
+            print("kernel_clock failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+    shard.barrier()
 
     if rank == 0:
         B, dw, dh, sw, sh = main_wl.B, main_wl.dw, main_wl.dh, main_wl.sw, main_wl.sh
@@ -495,7 +632,11 @@ def main():
                        "frames_per_gpu": B, "sharding": "frames split by rank, no collectives",
                        "buffer_sets_rotated": main_wl.nsets, "resident_bytes_per_gpu": main_wl.nsets * main_wl.set_bytes,
                        "kernel_source_sha": kernel_source_sha()},
-            "roofline": main_wl.roofline(launch_ms),
+            "roofline": main_wl.roofline(launch_ms, ceiling=ceiling, sclk_mhz=sclk),
+            # N > 1: the wall figure above is the slowest rank's K steps; these say whether a sub-linear curve comes from the
+            # kernels (a slow device) or from the host side (launch skew)
+            "kernel_ms_mean": round(float(launch_ms.mean()), 4), "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
+            "kernel_ms_min_over_ranks": round(kernel_ms_min, 4), "wall_ms_per_step_rank0": round(elapsed_local / args.steps * 1e3, 4),
         }
         if world == 1 and not args.no_cpu_baseline and main_wl.frames_np:
             gpu_out = main_wl.dsts[0][:len(main_wl.frames_np)].cpu().numpy()  # set 0 holds the seeded frames
@@ -512,7 +653,8 @@ def main():
             if (dt, ip, hom) == (args.dtype, args.interp, args.homography) and not planar:
                 continue
             w = Workload(args, dt, ip, rank, dev, planar=planar, homography=hom, device_frames=True)
-            variants.append(variant_line(w, n, max(5, args.warmup // 2), shard.barrier, label=dt if not planar else "u8 -> f32 planar"))
+            variants.append(variant_line(w, n, max(5, args.warmup // 2), shard.barrier, label=dt if not planar else "u8 -> f32 planar",
+                                         probe=not args.no_probe and not planar))
             del w
             torch.cuda.empty_cache()
         result["variants"] = variants

@@ -15,14 +15,19 @@ for rel in ("bev_amd/csrc/warp_kernels.hip", "bev_amd/csrc/warp_kernels.h", "bev
     with open(os.path.join(root, rel), "rb") as f:
         h.update(f.read())
 out = {"kernel_source_sha": h.hexdigest()[:16]}
-for tag in ("u8_linear", "f32_linear", "u8_nearest"):
+# keys as bench.py looks them up: <dtype>_<interp>[_<homography>]; files as tools/prof.sh tags them
+for key, tag in (("u8_linear", "u8_linear"), ("f32_linear", "f32_linear"), ("u8_nearest", "u8_nearest"), ("u8_linear_brno", "u8_brno"),
+                 ("f32_linear_brno", "f32_brno"), ("u8_nearest_brno", "u8_nearest_brno")):
     path = os.path.join(root, "profiles", "%s_%s_rocprofv3_summary.txt" % (rnd, tag))
+    if not os.path.exists(path):
+        continue
     txt = open(path).read()
     fetch = float(re.search(r"FETCH_SIZE\s+([\d.]+)", txt).group(1))
     write = float(re.search(r"WRITE_SIZE\s+([\d.]+)", txt).group(1))
-    avg = float(re.search(r"warp_\w+<.*?avg\s+([\d.]+) ns", txt).group(1))
-    out[tag] = {"hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "fetch_size_kib_raw": fetch, "write_size_kib": write,
-                "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)", "kernel_avg_ns_profiled": avg,
+    avg = float(re.search(r"warp_rows<.*?avg\s+([\d.]+) ns", txt).group(1))
+    sq = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(SQ_\w+|GRBM_GUI_ACTIVE)\s+([\d.]+)", txt, re.M)}
+    out[key] = {"hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "fetch_size_kib_raw": fetch, "write_size_kib": write,
+                "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)", "kernel_avg_ns_profiled": avg, "sq": sq,
                 "source": os.path.relpath(path, root)}
 with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)

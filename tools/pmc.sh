@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-configs $BENCH_ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
+  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-configs --no-probe $BENCH_ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done
 cd $R
 python3 - <<PY

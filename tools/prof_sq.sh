@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/profsq_$TAG
 mkdir -p $OUT
 [ -n "$BEVWARP_LIB" ] && [ "${BEVWARP_LIB:0:1}" != "/" ] && export BEVWARP_LIB=$R/$BEVWARP_LIB
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-configs $@"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-configs --no-probe $@"
 timeout -k 5 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py $ARGS > $OUT/pmc_sq.log 2>&1 || echo "pmc_sq failed"
 echo "pass 1 done"
 timeout -k 5 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1 || echo "pmc_sq2 failed"
