@@ -21,7 +21,7 @@ ONE JSON line (rank 0).  At N = 1 it also carries, measured in the same run:
              uint8 and float32), configs[4] (1080p -> 1024^2 uint8 warp + the 512 x 512 tracker launch, eager and replayed
              from a hipGraph), and the PCIe-inclusive frame pipeline
 `roofline.measured_ceiling_gbs` = what a pure streaming kernel with the headline's byte mix (its algorithmic source bytes
-read with plain 16-byte loads, its destination bytes written with non-temporal 16-byte stores -- the warp's access kinds)
+read with plain 16-byte loads, its destination bytes written with plain 16-byte stores -- the warp's access kinds)
 reaches in THIS process on THIS box, on the headline's own buffers, just before the headline runs (tools/streamprobe.hip;
 `measured_ceiling_nt_nt_gbs`: non-temporal loads as well, which gathers cannot use); `frac_of_measured` = achieved / that;
 `sclk_mhz` = the shader clock the chip held inside the warp kernel (s_memtime / s_memrealtime stamps of the diagnostic
@@ -208,7 +208,7 @@ def measured_ceiling(w):
     clk = torch.zeros(3, dtype=torch.int64, device=w.srcs[0].device)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = {"read_bytes": read_b, "write_bytes": write_b}
-    for label, ntl in (("plain_loads_nt_stores", 0), ("nt_loads_nt_stores", 1)):
+    for label, ntl, nts in (("plain_loads_plain_stores", 0, 0), ("plain_loads_nt_stores", 0, 1), ("nt_loads_nt_stores", 1, 1)):
         best = None
         for grid in (4096, 8192):
             k = [0]
@@ -216,7 +216,7 @@ def measured_ceiling(w):
             def launch():
                 i = k[0] % w.nsets
                 k[0] += 1
-                rc = lib.probe_stream(w.srcs[i].data_ptr(), read_b, w.dsts[i].data_ptr(), write_b, ntl, 1, grid, stream, clk.data_ptr())
+                rc = lib.probe_stream(w.srcs[i].data_ptr(), read_b, w.dsts[i].data_ptr(), write_b, ntl, nts, grid, stream, clk.data_ptr())
                 if rc:
                     raise RuntimeError("probe_stream failed: %d" % rc)
 
@@ -354,10 +354,10 @@ class Workload:
              "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
              "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
              "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
-        if ceiling is not None and "plain_loads_nt_stores" in ceiling:
-            r["measured_ceiling_gbs"] = ceiling["plain_loads_nt_stores"]["gbs"]
+        if ceiling is not None and "plain_loads_plain_stores" in ceiling:
+            r["measured_ceiling_gbs"] = ceiling["plain_loads_plain_stores"]["gbs"]  # the warp's own access kinds
             r["measured_ceiling_nt_nt_gbs"] = ceiling["nt_loads_nt_stores"]["gbs"]
-            r["frac_of_measured"] = round(achieved / ceiling["plain_loads_nt_stores"]["gbs"], 4)
+            r["frac_of_measured"] = round(achieved / ceiling["plain_loads_plain_stores"]["gbs"], 4)
             r["measured_ceiling"] = ceiling
         elif ceiling is not None:
             r["measured_ceiling"] = ceiling

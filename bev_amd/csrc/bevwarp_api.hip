@@ -33,6 +33,9 @@ int block_width(int dst_w, int dst_h) {
     return bw0 < dst_w ? bw0 : dst_w;
 }
 
+// division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
+uint32_t div_magic(uint64_t n_max, uint32_t d) { return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u; }
+
 }  // namespace
 
 #ifdef BEVWARP_CLOCK
@@ -179,13 +182,9 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
 #ifdef BEVWARP_TAIL_SPLIT  // experiments only
     a.tail_split = chunk > BEVWARP_TAIL_SPLIT ? BEVWARP_TAIL_SPLIT : 0;
 #endif
-    // division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
-    auto magic = [](uint64_t n_max, uint32_t d) -> uint32_t {
-        return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u;
-    };
-    a.tpf_magic = magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
-    a.tx_magic = magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
-    a.bw0_magic = magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
+    a.tpf_magic = div_magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
+    a.tx_magic = div_magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
+    a.bw0_magic = div_magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
     // wide stores: one lane writes its 4 consecutive 8-bit pixels (4 C bytes; 12-byte stores need 4-byte alignment) or 16
     // bytes of float data
     const int dst_align = (dtype == BEVWARP_U8 && !po) ? (channels == 4 ? 16 : (channels == 2 ? 8 : 4)) : 16;
@@ -240,15 +239,55 @@ int bevwarp_composite(const void* bg, const void* fg, const void* mask, void* ou
 int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_stride, const void* fg, const void* mask, int fg_h, int fg_w,
                            int64_t fg_row_stride, int64_t mask_row_stride, void* dst, int dst_h, int dst_w, int64_t dst_row_stride, int channels,
                            const double* M_inv_bg, const double* M_inv_cam, void* stream) {
+    using namespace bevwarp;
     if (!bg || !fg || !mask || !dst || !M_inv_bg || !M_inv_cam) return BEVWARP_ERR_BAD_ARG;
     if (bg_h <= 0 || bg_w <= 0 || fg_h <= 0 || fg_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
     if (channels < 1 || channels > 4) return BEVWARP_ERR_UNSUPPORTED;
     if (bg_row_stride < (int64_t)bg_w * channels || fg_row_stride < (int64_t)fg_w * channels || mask_row_stride < (int64_t)fg_w * channels ||
         dst_row_stride < (int64_t)dst_w * channels)
         return BEVWARP_ERR_BAD_ARG;
-    if (bg_w > 32767 || bg_h > 32767 || fg_w > 32767 || fg_h > 32767 || dst_h > 65535) return BEVWARP_ERR_TOO_LARGE;
-    const hipError_t e = bevwarp::launch_warp_composite(bg, bg_h, bg_w, bg_row_stride, fg, mask, fg_h, fg_w, fg_row_stride, mask_row_stride, dst, dst_h, dst_w,
-                                                        dst_row_stride, channels, M_inv_bg, M_inv_cam, block_width(dst_w, dst_h), (hipStream_t)stream);
+    if (bg_w > 32767 || bg_h > 32767 || fg_w > 32767 || fg_h > 32767 || dst_w > (1 << 20) || dst_h > (1 << 20)) return BEVWARP_ERR_TOO_LARGE;
+    const int64_t rs_max = bg_row_stride > fg_row_stride ? (bg_row_stride > mask_row_stride ? bg_row_stride : mask_row_stride)
+                                                         : (fg_row_stride > mask_row_stride ? fg_row_stride : mask_row_stride);
+    if (rs_max >= (1 << 24) || (int64_t)bg_h * bg_row_stride >= ((int64_t)1 << 31) || (int64_t)fg_h * fg_row_stride >= ((int64_t)1 << 31) ||
+        (int64_t)fg_h * mask_row_stride >= ((int64_t)1 << 31))
+        return BEVWARP_ERR_TOO_LARGE;  // (the kernel's 24-bit multiplies)
+    {  // the destination must not overlap a source (as for bevwarp_warp)
+        const uintptr_t d0 = (uintptr_t)dst, d1 = d0 + (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * channels;
+        const uintptr_t s0[3] = {(uintptr_t)bg, (uintptr_t)fg, (uintptr_t)mask};
+        const uint64_t sz[3] = {(uint64_t)(bg_h - 1) * bg_row_stride + (uint64_t)bg_w * channels, (uint64_t)(fg_h - 1) * fg_row_stride + (uint64_t)fg_w * channels,
+                                (uint64_t)(fg_h - 1) * mask_row_stride + (uint64_t)fg_w * channels};
+        for (int i = 0; i < 3; i++)
+            if (s0[i] < d1 && d0 < s0[i] + sz[i]) return BEVWARP_ERR_BAD_ARG;
+    }
+    WarpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = (const uint8_t*)bg, a.dst = (uint8_t*)dst, a.minv = M_inv_bg;
+    a.src_rs = bg_row_stride, a.dst_rs = dst_row_stride;
+    a.batch = 1, a.src_h = bg_h, a.src_w = bg_w, a.dst_h = dst_h, a.dst_w = dst_w;
+    a.m_stride = 0;
+    a.bw0 = block_width(dst_w, dst_h);
+    a.xsrc[0] = (const uint8_t*)fg, a.xsrc[1] = (const uint8_t*)mask;
+    a.xminv[0] = a.xminv[1] = M_inv_cam;
+    a.xsrc_rs[0] = fg_row_stride, a.xsrc_rs[1] = mask_row_stride;
+    a.xsrc_h[0] = a.xsrc_h[1] = fg_h, a.xsrc_w[0] = a.xsrc_w[1] = fg_w;
+    // one 12-wave workgroup per tile, one workgroup per CU: the tallest tile (<= the LDS copies' 16 rows) that still gives every
+    // CU a workgroup
+    const int tw = tile_width(BEVWARP_U8);
+    a.tiles_x = (dst_w + tw - 1) / tw;
+    const int64_t cus = resident_workgroups(BEVWARP_U8, channels, BEVWARP_LINEAR) / 4;
+    a.tile_h = composite_max_rows();
+    while (a.tile_h > rows_per_pass() && (int64_t)a.tiles_x * ((dst_h + a.tile_h - 1) / a.tile_h) < cus) a.tile_h /= 2;
+    a.tiles_per_frame = a.tiles_x * ((dst_h + a.tile_h - 1) / a.tile_h);
+    a.total_tiles = a.tiles_per_frame;
+    a.chunk = (int)((a.total_tiles + 7) / 8);
+    a.stagger = 0, a.tail_split = 0;
+    a.tpf_magic = div_magic((uint64_t)a.chunk * 8, (uint32_t)a.tiles_per_frame);
+    a.tx_magic = div_magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
+    a.bw0_magic = div_magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);
+    const int dst_align = channels == 4 ? 16 : (channels == 2 ? 8 : 4);
+    a.dst_vec_ok = ((uintptr_t)dst % dst_align == 0) && (dst_row_stride % dst_align == 0);
+    const hipError_t e = launch_warp_composite(a, channels, (hipStream_t)stream);
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
 

@@ -39,6 +39,21 @@ __device__ __forceinline__ void project_one(const H9& H, double x, double y, dou
     oy = tame ? Y * r : Y / Z;
 }
 
+#ifndef BEVWARP_PP_NT
+#define BEVWARP_PP_NT 1  // bit 0: non-temporal loads, bit 1: non-temporal stores.  A/B (tools/ab_points.py, profiles/r03_points_ab.txt): nt loads + plain stores is the fastest pair
+#endif
+template <typename V>
+__device__ __forceinline__ V pp_load(const V* p) {
+    if constexpr (BEVWARP_PP_NT & 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <typename V>
+__device__ __forceinline__ void pp_store(const V& v, V* p) {
+    if constexpr (BEVWARP_PP_NT & 2)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 typedef double pf64x2 __attribute__((ext_vector_type(2)));
 // (`out` may be `in`: every lane reads its own points before it writes them, and neither pointer is __restrict__)
@@ -58,12 +73,12 @@ __global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out
         }
         const int64_t pairs = n >> 1;
         for (int64_t i = t0; i < pairs; i += stride) {
-            const pf32x4 p = __builtin_nontemporal_load(reinterpret_cast<const pf32x4*>(in) + i);
+            const pf32x4 p = pp_load(reinterpret_cast<const pf32x4*>(in) + i);
             double ax, ay, bx, by;
             project_one(H, (double)p.x, (double)p.y, 1.0, ax, ay);
             project_one(H, (double)p.z, (double)p.w, 1.0, bx, by);
             const pf32x4 o = {(float)ax, (float)ay, (float)bx, (float)by};
-            __builtin_nontemporal_store(o, reinterpret_cast<pf32x4*>(out) + i);
+            pp_store(o, reinterpret_cast<pf32x4*>(out) + i);
         }
         if ((n & 1) && t0 == 0) {  // the odd last point
             double ax, ay;
@@ -73,11 +88,11 @@ __global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out
         }
     } else if constexpr (DIM == 2) {
         for (int64_t i = t0; i < n; i += stride) {
-            const pf64x2 p = __builtin_nontemporal_load(reinterpret_cast<const pf64x2*>(in) + i);
+            const pf64x2 p = pp_load(reinterpret_cast<const pf64x2*>(in) + i);
             double ox, oy;
             project_one(H, p.x, p.y, 1.0, ox, oy);
             const pf64x2 o = {ox, oy};
-            __builtin_nontemporal_store(o, reinterpret_cast<pf64x2*>(out) + i);
+            pp_store(o, reinterpret_cast<pf64x2*>(out) + i);
         }
     } else {
         for (int64_t i = t0; i < n; i += stride) {
@@ -263,11 +278,12 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
 }
 
 // ---- alpha composite (reference bev/tool/compo.py:16-23) ------------------------------------------------
-// out = uint8(min(round_half_even(fg * (mask / 255) + bg * (1 - mask / 255)), 255)), float64 like numpy; 16 bytes per lane.
+// out = uint8(min(round_half_even(fg * (mask / 255) + bg * (1 - mask / 255)), 255)) as numpy evaluates it in float64, computed
+// exactly in integers: with N = fg m + bg (255 - m) the float64 value is N / 255 up to 2.3e-13 and N / 255 is never closer than
+// 1 / 510 to a rounding boundary (2 N - 255 is odd), so the result is floor((N + 127) / 255) <= 255; (x * 0x8081) >> 23 == x / 255
+// for x < 2^16.  (Checked against the float64 expression for all 2^24 byte triples: tests/test_host_api.py.)  16 bytes per lane.
 __device__ __forceinline__ uint32_t composite_byte(uint32_t bg, uint32_t fg, uint32_t m) {
-    const double a = (double)m / 255.0;
-    const double v = rint((double)fg * a + (double)bg * (1.0 - a));
-    return (uint32_t)(v > 255.0 ? 255.0 : v);
+    return ((__umul24(fg, m) + __umul24(bg, 255u - m) + 127u) * 0x8081u) >> 23;
 }
 // (`out` may be `bg` or `fg`: a lane reads its 16 bytes of each input before it writes them; no pointer is __restrict__)
 __global__ __launch_bounds__(256) void composite_kernel(const uint8_t* bg, const uint8_t* fg, const uint8_t* mask, uint8_t* out, int64_t n, int vec_ok) {

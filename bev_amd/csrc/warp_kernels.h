@@ -31,15 +31,19 @@ struct WarpArgs {
     int planar;
     int64_t dst_ps;              // bytes between channel planes
     float pscale[4], pbias[4];
+    // composite (bevwarp_warp_composite): sources 1 and 2 (foreground, mask) beside src / minv / src_rs / src_h / src_w (background)
+    const uint8_t* xsrc[2];
+    const double* xminv[2];
+    int64_t xsrc_rs[2];
+    int xsrc_h[2], xsrc_w[2];
 };
 
 int tile_width(int dtype);   // destination pixels per row segment of one wave: 256 (8-bit) / 128 (float)
 int rows_per_pass();         // rows one pass of a workgroup's waves covers
 int resident_workgroups(int dtype, int channels, int interp);  // workgroups of this format's kernel the device holds at once
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream);
-hipError_t launch_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_rs, const void* fg, const void* mask, int fg_h, int fg_w, int64_t fg_rs,
-                                 int64_t mask_rs, void* dst, int dst_h, int dst_w, int64_t dst_rs, int channels, const double* m_bg, const double* m_cam,
-                                 int bw0, hipStream_t stream);
+hipError_t launch_warp_composite(const WarpArgs& a, int channels, hipStream_t stream);  // warp_rows<..., NSRC = 3>
+int composite_max_rows();    // tallest tile the composite's LDS copies hold
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream);
 hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, const double* H, int dtype, hipStream_t stream);

@@ -337,8 +337,14 @@ constexpr int waves_per_simd_of(bool is_u8, int channels, int interp) {
 }
 template <typename T, int C, int INTERP>
 constexpr int waves_per_simd() { return waves_per_simd_of(sizeof(T) == 1, C, INTERP); }
-template <typename T, int C, int INTERP, bool RS4, bool PLANAR>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_simd<T, C, INTERP>(), 8))) void warp_rows(const WarpArgs a) {
+// NSRC = 3 is warp_composite (bev/tool/compo.py:26-49) in one launch: a workgroup of 12 waves, four per source -- waves 0-3
+// warp the background, 4-7 the foreground, 8-11 its mask, each group exactly as a workgroup of the plain kernel would, every
+// group through its own homography and its own tile classification -- into an LDS copy of the tile instead of memory; after one
+// barrier all twelve blend the three LDS tiles and store the composite.  The three warped images never exist in memory and
+// every pixel is, by construction, what three bevwarp_warp calls produce.
+constexpr int kCompositeRows = 16;  // tallest tile of the composite (its three LDS copies: 48 KB)
+template <typename T, int C, int INTERP, bool RS4, bool PLANAR, int NSRC = 1>
+__global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC > 1 ? 3 : waves_per_simd<T, C, INTERP>(), 8))) void warp_rows(const WarpArgs a) {
     constexpr int PPL = pixels_per_lane<T>();
     constexpr int TW = 64 * PPL;                                 // tile width
     constexpr int kStrips = PPL;                                 // 64-pixel column strips of a tile (block ownership)
@@ -358,7 +364,10 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                                                  // up to 3 bytes early: never before its row)
     constexpr int TRW = 64 * PPL * (sizeof(T) == 1 ? 1 : C);  // dwords of a wave's transposition row
     static_assert(!RS4 || kAligned, "RS4 only qualifies the aligned-window variant");
-    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves][TRW];
+    static_assert(NSRC == 1 || (NSRC == 3 && sizeof(T) == 1 && INTERP == kLinear && !PLANAR), "the composite is three 8-bit bilinear warps");
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][TRW];
+    // (composite only) the warped tiles, one packed pixel per dword: [source][row of the tile][pixel]
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[NSRC > 1 ? NSRC * kCompositeRows * TW : 4];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
 #ifdef BEVWARP_CLOCK
     struct ClockStamp {
@@ -391,29 +400,41 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
     const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;
     const int x0 = (int)tx * TW, y0 = (int)ty * a.tile_h + (half == 1 ? a.tile_h / 2 : 0);
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
-    const uint8_t* __restrict__ frame = a.src + (int64_t)frame_idx * a.src_fs;
+    const int lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
+    const int wave = NSRC > 1 ? (wave_all & (kWaves - 1)) : wave_all, sid = NSRC > 1 ? (wave_all >> 2) : 0;  // wave of its group of four / source
+    // this wave's source (composite: background, foreground or mask; frames of one launch otherwise)
+    const uint8_t* src_base = a.src;
+    const double* m_base = a.minv;
+    int64_t src_rs = a.src_rs;
+    int src_w = a.src_w, src_h = a.src_h;
+    if constexpr (NSRC > 1) {
+        if (sid > 0) {
+            src_base = a.xsrc[sid - 1], m_base = a.xminv[sid - 1], src_rs = a.xsrc_rs[sid - 1];
+            src_w = a.xsrc_w[sid - 1], src_h = a.xsrc_h[sid - 1];
+        }
+    }
+    const uint8_t* __restrict__ frame = src_base + (int64_t)frame_idx * a.src_fs;
     uint8_t* __restrict__ dframe = a.dst + (int64_t)frame_idx * a.dst_fs;
-    const double* __restrict__ M = a.minv + (int64_t)frame_idx * a.m_stride;
+    const double* __restrict__ M = m_base + (int64_t)frame_idx * a.m_stride;
     const int y_last = min(y0 + (half >= 0 ? a.tile_h / 2 : a.tile_h), a.dst_h) - 1;
     if (y0 > y_last) return;  // (the lower half of a ragged last tile may be empty)
 
     SrcView view;
     view.frame = frame;
-    view.rs = a.src_rs;
-    view.w = a.src_w;
-    view.h = a.src_h;
+    view.rs = src_rs;
+    view.w = src_w;
+    view.h = src_h;
 #pragma unroll
     for (int k = 0; k < 4; k++) view.bf[k] = a.bval_f[k];
     view.bu = (uint32_t)a.bval_u8[0] | ((uint32_t)a.bval_u8[1] << 8) | ((uint32_t)a.bval_u8[2] << 16) | ((uint32_t)a.bval_u8[3] << 24);
 
     // -- limits of unguarded loads
-    const int sx_lim = (int)(((int64_t)a.src_w * PBs - LOADB) / PBs);   // largest sx with sx*PBs + LOADB <= w*PBs
-    const int sxw_lim = (int)(((int64_t)a.src_w * PBs - WINB) / PBs);   // same for the FAST rows' windows
-    const int sy_lim = a.src_h - (INTERP == kLinear ? 2 : 1);
-    const bool any_unguarded = (int64_t)a.src_w * PBs >= LOADB && sy_lim >= 0;
+    const int sx_lim = (int)(((int64_t)src_w * PBs - LOADB) / PBs);   // largest sx with sx*PBs + LOADB <= w*PBs
+    const int sxw_lim = (int)(((int64_t)src_w * PBs - WINB) / PBs);   // same for the FAST rows' windows
+    const int sy_lim = src_h - (INTERP == kLinear ? 2 : 1);
+    const bool any_unguarded = (int64_t)src_w * PBs >= LOADB && sy_lim >= 0;
     const uint32_t sx_max = any_unguarded ? (uint32_t)sx_lim : 0u, sy_max = any_unguarded ? (uint32_t)sy_lim : 0u;
-    const bool can_fast = (int64_t)a.src_w * PBs >= 32 && sxw_lim >= 2 * kM && sy_lim >= 2 * kM;
+    const bool can_fast = (int64_t)src_w * PBs >= 32 && sxw_lim >= 2 * kM && sy_lim >= 2 * kM;
 
     // -- wave-uniform terms of the fast chain (numerators carry the 2^32 of the fixed-point form)
     auto uniform_f64 = [](double v) {  // a wave-uniform double, moved to scalar registers
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
 
     // -- byte offsets of FAST rows straight from the high dwords (24-bit multiplies: the host guarantees row stride < 2^24
     // and frames < 2 GiB; a FAST row has 0 <= sx, sy < 2^15, so the low 24 bits of a high dword are 0x380000 + s)
-    const uint32_t rs32 = (uint32_t)a.src_rs;
+    const uint32_t rs32 = (uint32_t)src_rs;
     const uint32_t fa = kAligned ? (uint32_t)(reinterpret_cast<uintptr_t>(frame) & 3u) : 0u;
     const uint8_t* frame_al = frame - fa;  // 4-byte aligned (frames need not be)
     const uint32_t kOff = fa - 0x380000u * (rs32 + (uint32_t)PBs);
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                                 (hyd ^ kHiExp)) >> 20) == 0;  // every corner inside the binade
             const int sx_hi = max(max(sxa, sxb), max(sxc, sxd)), sx_lo = min(min(sxa, sxb), min(sxc, sxd));
             const int sy_hi = max(max(sya, syb), max(syc, syd)), sy_lo = min(min(sya, syb), min(syc, syd));
-            const bool out = sx_hi <= -3 || sx_lo > a.src_w || sy_hi <= -3 || sy_lo > a.src_h;
+            const bool out = sx_hi <= -3 || sx_lo > src_w || sy_hi <= -3 || sy_lo > src_h;
             // kEdge: W of one sign and both ends representable => every pixel between them is (the map is monotone along
             // the segment), taps need guards
             cls = !(e_ok && w_ok) ? kSlow : (out ? kOut : kEdge);
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
     };
 
-    uint32_t* wtr = &s_tr[wave][0];
+    uint32_t* wtr = &s_tr[wave_all][0];
     // blend one pixel from its taps -- w0 / w1 = the LOADB bytes of the upper / lower tap row starting AT the left tap -- into
     // the wave's LDS row (pixel 64 j + lane of the segment)
     auto blend_put = [&](int j, const uint32_t (&w0)[NEED], const uint32_t (&w1)[NEED], uint32_t fx, uint32_t fy) __attribute__((always_inline)) {
@@ -728,7 +749,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
             const int sx = X >> SH, sy = Y >> SH;
             const uint32_t fx = (uint32_t)X & 31u, fy = (uint32_t)Y & 31u;
             constexpr int kTap = INTERP == kLinear ? 1 : 0;  // taps reach sx + kTap, sy + kTap
-            const bool all_out = sx < -kTap || sx >= a.src_w || sy < -kTap || sy >= a.src_h;
+            const bool all_out = sx < -kTap || sx >= src_w || sy < -kTap || sy >= src_h;
             Pixel<T, C> v;
             if (inb[j]) {
                 if constexpr (sizeof(T) == 1) {
@@ -793,9 +814,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         }
     };
 
-    // -- stores.  The destination is written once and never read back by this kernel: non-temporal stores keep it from
-    // displacing source lines in L2 / MALL.  Lanes of a ragged last tile (and every lane when the destination's layout
-    // does not admit the wide stores) fall back to element stores.
+    // -- stores.  Plain (default-policy) wide stores: the destination is written once and never read back by this kernel, but
+    // non-temporal stores -- round 2's choice -- measure SLOWER on every format here (A/B of four builds interleaved on one
+    // box, profiles/r03_store_ab.txt: float32 keystone 192.8 -> 183.7 us, 8-bit bilinear 73.7 -> 72.2, nearest 58.3 -> 55.6).
+    // Lanes of a ragged last tile (and every lane when the destination's layout does not admit the wide stores) fall back to
+    // element stores.  (Also measured and not kept: the wide store as ONE unconditional buffer_store whose masked lanes get an
+    // out-of-range offset, so that the compiler's vmcnt accounting sees it -- nearest -4 %, bilinear and float +4 %.)
     auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {  // xs = first pixel of the segment / block
         constexpr bool kBlk = decltype(own)::blk;
         const int seg_px = min(kBlk ? 64 : TW, a.dst_w - xs);  // valid pixels of a row of the segment / block
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                                (float)((p[2] >> (8 * k)) & 0xffu) * sc + bi, (float)((p[3] >> (8 * k)) & 0xffu) * sc + bi};
                     float* dk = reinterpret_cast<float*>(dp + k * a.dst_ps);
                     if (__builtin_expect(lane_vec, 1)) {
-                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dk));
+                        *reinterpret_cast<f32x4*>(dk) = o;
                     } else {
                         for (int i = 0; i < lane_px; i++) dk[i] = o[i];
                     }
@@ -826,19 +850,23 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                 return;
             }
             if (kBlk && y + st_row > y_last) return;
+            if constexpr (NSRC > 1) {  // composite: the lane's four packed pixels go to this source's LDS copy of the tile
+                *reinterpret_cast<uint4*>(&s_tile[(sid * kCompositeRows + (y + st_row - y0)) * TW + (st_x - x0)]) = out[0];
+                return;
+            }
             uint8_t* d = dframe + (int64_t)(y + st_row) * a.dst_rs + (int64_t)st_x * C;
             if (__builtin_expect(lane_vec, 1)) {
                 if constexpr (C == 1) {
-                    __builtin_nontemporal_store(p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24), reinterpret_cast<uint32_t*>(d));
+                    *reinterpret_cast<uint32_t*>(d) = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
                 } else if constexpr (C == 2) {
                     u32x2 o = {p[0] | (p[1] << 16), p[2] | (p[3] << 16)};
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(d));
+                    *reinterpret_cast<u32x2*>(d) = o;
                 } else if constexpr (C == 3) {
                     u32x3 o = {p[0] | (p[1] << 24), (p[1] >> 8) | (p[2] << 16), (p[2] >> 16) | (p[3] << 8)};
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(d));
+                    *reinterpret_cast<u32x3*>(d) = o;
                 } else {
                     u32x4 o = {p[0], p[1], p[2], p[3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(d));
+                    *reinterpret_cast<u32x4*>(d) = o;
                 }
             } else {
                 for (int i = 0; i < lane_px; i++)
@@ -854,7 +882,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
 #pragma unroll
                 for (int k = 0; k < C; k++) {
                     float* dk = reinterpret_cast<float*>(dframe + k * a.dst_ps + (int64_t)py * a.dst_rs) + px;
-                    __builtin_nontemporal_store(o[j * C + k] * a.pscale[k] + a.pbias[k], dk);
+                    *dk = o[j * C + k] * a.pscale[k] + a.pbias[k];
                 }
             }
         } else {
@@ -873,7 +901,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
                 float* drow = reinterpret_cast<float*>(dframe + (int64_t)(y + r) * a.dst_rs) + (int64_t)xs * C;
                 if (__builtin_expect(a.dst_vec_ok && 4 * qr + 4 <= nfl, 1)) {
                     u32x4 o = {out[u].x, out[u].y, out[u].z, out[u].w};
-                    __builtin_nontemporal_store(o, &reinterpret_cast<u32x4*>(drow)[qr]);
+                    *(&reinterpret_cast<u32x4*>(drow)[qr]) = o;
                 } else {
                     const uint32_t f[4] = {out[u].x, out[u].y, out[u].z, out[u].w};
                     for (int i = 0; i < 4 && 4 * qr + i < nfl; i++) reinterpret_cast<uint32_t*>(drow)[4 * qr + i] = f[i];
@@ -913,7 +941,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         // outside: all four corners beyond the same frame edge (coordinates representable, W sane) -- the border value
         const bool c_rep = c_w && (((chx ^ kHiExp) | (chy ^ kHiExp)) >> 20) == 0;
         auto all4 = [](bool v) { return ((uint32_t)__ballot(v) & 0xFu) == 0xFu; };
-        tile_out = one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > a.src_w) || all4(csy <= -3) || all4(csy > a.src_h));
+        tile_out = one_sign && all4(c_rep) && (all4(csx <= -3) || all4(csx > src_w) || all4(csy <= -3) || all4(csy > src_h));
         // Turned footprints.  A row gather's 64 lanes lie on a source line that crosses dy source rows per 64 destination
         // pixels -- a cache line each once dy passes the lines the run would touch anyway -- and pixels sqrt(dx^2 + dy^2) / 64 apart;
         // a 16 x 4 patch of the same 64 pixels crosses a quarter of them.  Measured crossover (A/B over angles and
@@ -967,6 +995,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         const double lx = (double)(patches ? lane & (PWd - 1) : lane), ly = patches ? (double)(lane / PWd) : 0.0;
         cx0 = __builtin_fma(RX, ly, (m0 * kTwo32) * lx), cy0 = __builtin_fma(RY, ly, (m3 * kTwo32) * lx), cw0 = __builtin_fma(RW, ly, m6 * lx);
     }
+    auto run_tile = [&]() __attribute__((always_inline)) {
     if (tile_out) {  // every pixel of the tile is the border value
         Pass p;
         if (!first_pass(BlkSeg{}, p)) return;
@@ -1101,83 +1130,55 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(waves_per_s
         edge_tile(PatSeg{});
     else
         edge_tile(BlkSeg{});
-}
-
-// ===================================================================================================
-// warp_composite<C>: composite_bev_img in ONE launch (reference bev/tool/compo.py:26-49): every destination pixel samples
-// the background through M_bg and the foreground AND its mask through M_cam (one coordinate pair for both), and blends
-// in registers -- fg * (m / 255) + bg * (1 - m / 255) in float64, round half even, clip -- so none of the three warped
-// images ever exists in memory.  8-bit, bilinear, zero border (what the reference's three warpPerspective calls use).
-// One pixel per lane, lanes along the row; coordinates by the fast chain with the same tie window and exact fallback as
-// warp_rows, taps unguarded when all four lie inside the frame and guarded otherwise.
-// ===================================================================================================
-struct CompositeArgs {
-    const uint8_t *bg, *fg, *mask;
-    uint8_t* dst;
-    const double *m_bg, *m_cam;  // device, inverse matrices
-    int64_t bg_rs, fg_rs, mask_rs, dst_rs;
-    int bg_h, bg_w, fg_h, fg_w, dst_h, dst_w, bw0;
-};
-
-template <int C>
-__device__ __forceinline__ uint32_t sample_u8_linear(const uint8_t* __restrict__ img, int64_t rs, int w, int h, int X, int Y) {
-    const int sx = X >> kInterBits, sy = Y >> kInterBits;
-    const uint32_t fx = (uint32_t)X & 31u, fy = (uint32_t)Y & 31u;
-    constexpr int LB = (2 * C + 3) & ~3;  // bytes of a tap pair, whole dwords
-    if ((uint32_t)sx <= (uint32_t)((int64_t)w * C - LB) / C && (uint32_t)sy < (uint32_t)(h - 1) && (int64_t)w * C >= LB && h >= 2) {
-        uint32_t t[LB / 4], u[LB / 4];
-        const uint8_t* p = img + (int64_t)sy * rs + (int64_t)sx * C;
-        __builtin_memcpy(t, p, LB);
-        __builtin_memcpy(u, p + rs, LB);
-        if constexpr (C == 3) return blend_u8_rgb_window(t[0], t[1], u[0], u[1], fx, fy);
-        if constexpr (C == 4) return blend_u8_packed<C>(t[0], t[1], u[0], u[1], fx, fy);
-        if constexpr (C < 3) return blend_u8_packed<C>(t[0], t[0] >> (8 * C), u[0], u[0] >> (8 * C), fx, fy);
-    }
-    SrcView v;
-    v.frame = img, v.rs = rs, v.w = w, v.h = h, v.bu = 0;
-    for (int k = 0; k < 4; k++) v.bf[k] = 0.f;
-    return sample_global<uint8_t, C, kLinear>(v, X, Y).packed;
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void warp_composite(const CompositeArgs a) {
-    using F = Fix<kLinear>;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= a.dst_w) return;
-    // the two maps: (X, Y) in 1/32 px of the background frame and of the camera frame
-    int Xs[2], Ys[2];
+    };  // run_tile
+    run_tile();
+    if constexpr (NSRC > 1) {
+        // -- composite_reg_img (bev/tool/compo.py:16-23) on the three LDS tiles.  The reference evaluates
+        //   round(fg * (m / 255) + bg * (1 - m / 255)) in float64 and clips to 255; with N = fg m + bg (255 - m) that value is N / 255
+        // up to 2.3e-13, while N / 255 is never closer than 1 / 510 to a rounding boundary (2 N - 255 is odd), so the result is
+        // exactly floor((N + 127) / 255), which never exceeds 255: integer arithmetic, no division ((x * 0x8081) >> 23 == x / 255
+        // for x < 2^16).
+        __syncthreads();
+        const int rows = y_last - y0 + 1;
+        for (int u = tid; u < rows * 64; u += kWG * NSRC) {
+            const int r = u >> 6, x = x0 + 4 * (u & 63);
+            if (x >= a.dst_w) continue;
+            const uint4 pb = *reinterpret_cast<const uint4*>(&s_tile[(0 * kCompositeRows + r) * TW + (x - x0)]);
+            const uint4 pf = *reinterpret_cast<const uint4*>(&s_tile[(1 * kCompositeRows + r) * TW + (x - x0)]);
+            const uint4 pm = *reinterpret_cast<const uint4*>(&s_tile[(2 * kCompositeRows + r) * TW + (x - x0)]);
+            const uint32_t b4[4] = {pb.x, pb.y, pb.z, pb.w}, f4[4] = {pf.x, pf.y, pf.z, pf.w}, m4[4] = {pm.x, pm.y, pm.z, pm.w};
+            uint32_t p[4];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const double* __restrict__ M = q == 0 ? a.m_bg : a.m_cam;
-        const double xd = (double)x, yd = (double)y;
-        const double W = __builtin_fma(M[6], xd, __builtin_fma(M[7], yd, M[8]));
-        const double r = rcp_newton(W) * kTwo32;
-        const double tx = __builtin_fma(__builtin_fma(M[0], xd, __builtin_fma(M[1], yd, M[2])), r, F::kMagic);
-        const double ty = __builtin_fma(__builtin_fma(M[3], xd, __builtin_fma(M[4], yd, M[5])), r, F::kMagic);
-        const uint32_t hx = (uint32_t)__double2hiint(tx), lx = (uint32_t)__double2loint(tx), hy = (uint32_t)__double2hiint(ty), ly = (uint32_t)__double2loint(ty);
-        const uint32_t we = ((uint32_t)__double2hiint(W) >> 20) & 0x7ffu;
-        // trust the fast chain inside the binade, away from the tie windows, for a sane W; else the reference's chain
-        if ((((hx ^ kHiExp) | (hy ^ kHiExp)) >> 20) == 0 && (lx & F::kTieMask) != 0 && (ly & F::kTieMask) != 0 && we - 824u <= 398u) {
-            Xs[q] = fix_to_int<kLinear>(hx, lx);
-            Ys[q] = fix_to_int<kLinear>(hy, ly);
-        } else {
-            const int bx = (x / a.bw0) * a.bw0;
-            double X0, Y0, W0;
-            row_terms(M, bx, y, X0, Y0, W0);
-            const double x1 = (double)(x - bx);
-            map_pixel_exact<kLinear>(X0 + M[0] * x1, Y0 + M[3] * x1, W0 + M[6] * x1, Xs[q], Ys[q]);
+            for (int i = 0; i < 4; i++) {
+                p[i] = 0;
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    const uint32_t m = (m4[i] >> (8 * k)) & 0xffu, f = (f4[i] >> (8 * k)) & 0xffu, b = (b4[i] >> (8 * k)) & 0xffu;
+                    const uint32_t n = __umul24(f, m) + __umul24(b, 255u - m) + 127u;
+                    p[i] |= ((n * 0x8081u) >> 23) << (8 * k);
+                }
+            }
+            uint8_t* d = dframe + (int64_t)(y0 + r) * a.dst_rs + (int64_t)x * C;
+            const int lane_px = min(4, a.dst_w - x);
+            if (__builtin_expect(a.dst_vec_ok && lane_px == 4, 1)) {
+                if constexpr (C == 1) {
+                    *reinterpret_cast<uint32_t*>(d) = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
+                } else if constexpr (C == 2) {
+                    u32x2 o = {p[0] | (p[1] << 16), p[2] | (p[3] << 16)};
+                    *reinterpret_cast<u32x2*>(d) = o;
+                } else if constexpr (C == 3) {
+                    u32x3 o = {p[0] | (p[1] << 24), (p[1] >> 8) | (p[2] << 16), (p[2] >> 16) | (p[3] << 8)};
+                    *reinterpret_cast<u32x3*>(d) = o;
+                } else {
+                    u32x4 o = {p[0], p[1], p[2], p[3]};
+                    *reinterpret_cast<u32x4*>(d) = o;
+                }
+            } else {
+                for (int i = 0; i < lane_px; i++)
+#pragma unroll
+                    for (int k = 0; k < C; k++) d[i * C + k] = (uint8_t)(p[i] >> (8 * k));
+            }
         }
-    }
-    const uint32_t pb = sample_u8_linear<C>(a.bg, a.bg_rs, a.bg_w, a.bg_h, Xs[0], Ys[0]);
-    const uint32_t pf = sample_u8_linear<C>(a.fg, a.fg_rs, a.fg_w, a.fg_h, Xs[1], Ys[1]);
-    const uint32_t pm = sample_u8_linear<C>(a.mask, a.mask_rs, a.fg_w, a.fg_h, Xs[1], Ys[1]);
-    uint8_t* d = a.dst + (int64_t)y * a.dst_rs + (int64_t)x * C;
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-        // composite_reg_img, compo.py:16-23, in float64 like numpy: two products, one sum, round half even, clip
-        const double al = (double)((pm >> (8 * k)) & 0xffu) / 255.0;
-        const double v = rint((double)((pf >> (8 * k)) & 0xffu) * al + (double)((pb >> (8 * k)) & 0xffu) * (1.0 - al));
-        d[k] = (uint8_t)(v > 255.0 ? 255.0 : v);
     }
 }
 
@@ -1279,24 +1280,18 @@ hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, h
     return hipGetLastError();
 }
 
-hipError_t launch_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_rs, const void* fg, const void* mask, int fg_h, int fg_w, int64_t fg_rs,
-                                 int64_t mask_rs, void* dst, int dst_h, int dst_w, int64_t dst_rs, int channels, const double* m_bg, const double* m_cam,
-                                 int bw0, hipStream_t stream) {
+hipError_t launch_warp_composite(const WarpArgs& a, int channels, hipStream_t stream) {
     (void)hipGetLastError();
-    CompositeArgs a;
-    a.bg = (const uint8_t*)bg, a.fg = (const uint8_t*)fg, a.mask = (const uint8_t*)mask, a.dst = (uint8_t*)dst;
-    a.m_bg = m_bg, a.m_cam = m_cam;
-    a.bg_rs = bg_rs, a.fg_rs = fg_rs, a.mask_rs = mask_rs, a.dst_rs = dst_rs;
-    a.bg_h = bg_h, a.bg_w = bg_w, a.fg_h = fg_h, a.fg_w = fg_w, a.dst_h = dst_h, a.dst_w = dst_w, a.bw0 = bw0;
-    const dim3 block(256), grid((dst_w + 255) / 256, dst_h);
+    const dim3 grid((unsigned)(8 * a.chunk)), block(kWG * 3);
     switch (channels) {
-        case 1: hipLaunchKernelGGL(warp_composite<1>, grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(warp_composite<2>, grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(warp_composite<3>, grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL(warp_composite<4>, grid, block, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((warp_rows<uint8_t, 1, kLinear, false, false, 3>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((warp_rows<uint8_t, 2, kLinear, false, false, 3>), grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((warp_rows<uint8_t, 3, kLinear, false, false, 3>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((warp_rows<uint8_t, 4, kLinear, false, false, 3>), grid, block, 0, stream, a); break;
     }
     return hipGetLastError();
 }
+int composite_max_rows() { return kCompositeRows; }
 
 hipError_t launch_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* minv,
                             int m_stride, int bw0, int interp, hipStream_t stream) {

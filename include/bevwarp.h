@@ -53,7 +53,7 @@ typedef enum bevwarp_status {
     BEVWARP_OK = 0,
     BEVWARP_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, misaligned or overlapping strides */
     BEVWARP_ERR_UNSUPPORTED = -2,  /* dtype / channel count / interpolation outside the supported set    */
-    BEVWARP_ERR_TOO_LARGE = -3,    /* source side > 32767 px (fixed-point map range of the algorithm)   */
+    BEVWARP_ERR_TOO_LARGE = -3,    /* source side > 32767 px (fixed-point map range), a source row >= 16 MiB or frame >= 2 GiB */
     BEVWARP_ERR_NOT_FINITE = -4,   /* homography contains NaN / Inf                                      */
     BEVWARP_ERR_HIP = -5           /* a HIP runtime call failed; see bevwarp_last_hip_error()            */
 } bevwarp_status;

@@ -368,3 +368,17 @@ def test_resize_matrix_matches_calib_scale():
         if align:  # (1919/959 != 1079/539: not aspect-preserving in this convention)
             continue
         np.testing.assert_allclose(Hs / Hs[2, 2], H / H[2, 2], rtol=1e-9, atol=1e-9)
+
+
+def test_composite_integer_form_equals_the_float64_expression():
+    """composite_reg_img (/root/reference/bev/tool/compo.py:16-23): round(fg * (m / 255) + bg * (1 - m / 255)) in float64, clipped
+    to 255.  The HIP kernels evaluate it as ((fg m + bg (255 - m) + 127) * 0x8081) >> 23 -- exact integer arithmetic; here for
+    every one of the 2^24 (fg, bg, mask) byte triples against the reference's own numpy expression."""
+    f = np.arange(256, dtype=np.float64)[:, None, None]
+    b = np.arange(256, dtype=np.float64)[None, :, None]
+    m = np.arange(256, dtype=np.float64)[None, None, :] / 255
+    ref = (f * m + b * (1 - m)).round()
+    ref[ref > 255] = 255
+    fi, bi, mi = (np.arange(256, dtype=np.int64).reshape(s) for s in ((256, 1, 1), (1, 256, 1), (1, 1, 256)))
+    got = ((fi * mi + bi * (255 - mi) + 127) * 0x8081) >> 23
+    np.testing.assert_array_equal(got, ref.astype(np.int64))
