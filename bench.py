@@ -274,6 +274,21 @@ def event_times(fn, n, warm):
     return np.array([a.elapsed_time(b) for a, b in ev]) * 1e-3
 
 
+def back_to_back_us(fn, n=500, warm=20):
+    """Mean time per call (us) of n calls queued back to back between ONE pair of HIP events: what a camera loop sees.  (Per-call
+    event pairs add two hipEventRecord calls per iteration, which on this runtime cost more host time than a 10-us kernel.)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / n
+
+
 class Workload:
     """One dtype / interpolation variant of a batched warp resident on one GPU."""
 
@@ -317,6 +332,16 @@ class Workload:
         self.minv = warp.device_inverse(self.Ms, dev)
         counts, touched = warp.footprint((sh, sw), self.Ms, (dw, dh), flags=self.interp, device=dev)
         self.footprint_px = int(counts.sum().item())
+        # The same footprint at the granularity memory is fetched in: distinct 64-byte sectors / 128-byte lines of the source
+        # frames that hold at least one touched pixel.  Taps of a strongly minified far field lie 3-8 pixels apart, so the bytes
+        # that MUST cross the HBM interface exceed the touched pixels' own: `traffic` is to be read against this figure too.
+        row_bytes = sw * C * esz
+        self.sector_bytes = {}
+        if row_bytes % 128 == 0:
+            bm = touched.view(-1, sw, 1).expand(-1, sw, C * esz).reshape(-1, row_bytes)  # byte mask, one row per source row
+            for g in (64, 128):
+                self.sector_bytes[g] = int(bm.reshape(-1, row_bytes // g, g).any(dim=2).sum().item()) * g
+            del bm
         del touched
         self.algo_bytes = B * dh * dw * C * out_esz + self.footprint_px * C * esz
 
@@ -352,6 +377,8 @@ class Workload:
              "traffic": None if rec is None else rec.get("hbm_bytes_per_launch"),
              "kernel": "warp_rows<%s,3,%s>%s" % ("uint8" if self.esz == 1 else "float", self.interp_name, " -> float32 planes" if self.planar else ""),
              "algorithmic_bytes_per_launch": self.algo_bytes, "footprint_px_per_launch": self.footprint_px,
+             "footprint_64B_sector_bytes": self.sector_bytes.get(64), "footprint_128B_line_bytes": self.sector_bytes.get(128),
+             "min_hbm_bytes_at_64B_granularity": (self.sector_bytes[64] + self.algo_bytes - self.footprint_px * self.C * self.esz) if self.sector_bytes else None,
              "kernel_ms_mean": round(kernel_s * 1e3, 4), "kernel_ms_min": round(float(launch_ms.min()), 4),
              "kernel_mpix_per_s": round(self.B * self.dw * self.dh / 1e6 / kernel_s, 1)}
         if ceiling is not None and "plain_loads_plain_stores" in ceiling:
@@ -403,11 +430,21 @@ def config0(dev):
     mpix = dw * dh / 1e6
     src, out = torch.from_numpy(img).to(dev), torch.empty((dh, dw, 3), dtype=torch.uint8, device=dev)
     minv = warp.device_inverse(M, dev)
-    t = event_times(lambda: warp.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv), 200, 20)
+    call = lambda: warp.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv)  # noqa: E731
+    t = event_times(call, 200, 20)
+    b2b = back_to_back_us(call)
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        call()
+    host_us = (time.perf_counter() - t0) / 2000 * 1e6  # (the queue back-pressures once it is full: an upper bound of the Python entry's cost)
+    torch.cuda.synchronize()
     exp = co.warp_perspective(img, M, (dw, dh), 1, nthreads=1)
     res = {"workload": "one 1280x720x3 uint8 frame -> 512x512 BEV, bilinear, synth-brno homography",
-           "gpu_resident": {"us_median": round(float(np.median(t)) * 1e6, 2), "us_min": round(float(t.min()) * 1e6, 2),
-                            "Mpix_per_s": round(mpix / float(np.median(t)), 1), "matches_oracle": bool(np.array_equal(out.cpu().numpy(), exp))}}
+           "gpu_resident": {"us_median": round(b2b, 2), "us_per_call_event_pairs_median": round(float(np.median(t)) * 1e6, 2),
+                            "us_min_event_pair": round(float(t.min()) * 1e6, 2), "host_us_per_call": round(host_us, 2),
+                            "what": "bev_amd.warp.warp_perspective (the Python entry, validated-launch cache) called back to back; us_median = "
+                                    "500 calls between one pair of HIP events / 500",
+                            "Mpix_per_s": round(mpix / (b2b * 1e-6), 1), "matches_oracle": bool(np.array_equal(out.cpu().numpy(), exp))}}
     hs = []
     for _ in range(25):
         t0 = time.perf_counter()
@@ -525,7 +562,10 @@ def composite_config(dev):
     H_world2bev = np.array([[0.0, 24.0, 512.0], [-24.0, 0.0, 900.0], [0.0, 0.0, 1.0]])
     H_img2world_fix = np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)) @ np.array([[1, 0, 3.0], [0, 1, -2.0], [0, 0, 1]])
     bg, fg, mask = (torch.from_numpy(wl.frame(i, 1080, 1920, np.uint8)).to(dev) for i in (0, 1, 2))
+    Hb_ = H_world2bev.dot(H_img2world_fix)
     one = event_times(lambda: composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 1024, 1024), 100, 10)
+    one_b2b = back_to_back_us(lambda: composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 1024, 1024), 200, 10)
+    warp_b2b = back_to_back_us(lambda: warp.warp_perspective(bg, Hb_, (1024, 1024)), 200, 10)
     Hb = H_world2bev.dot(H_img2world_fix)
     Hc = H_world2bev.dot(np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)))
 
@@ -536,6 +576,8 @@ def composite_config(dev):
     same = bool(torch.equal(three(), composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 1024, 1024)[0]))
     return {"workload": "composite_bev_img: 1080p background + 1080p foreground + mask -> one 1024x1024 uint8 composite (device resident)",
             "one_launch_us": round(float(np.median(one)) * 1e6, 1), "three_warps_plus_blend_us": round(float(np.median(thr)) * 1e6, 1),
+            "one_launch_back_to_back_us": round(one_b2b, 1), "one_u8_warp_same_destination_back_to_back_us": round(warp_b2b, 1),
+            "kernel": "warp_rows<uint8,3,linear,NSRC=3> (12 waves per workgroup; rocprofv3 kernel time: profiles/r03_geom_rocprofv3_summary.txt)",
             "one_launch_equals_three_warps_plus_blend": same}
 
 

@@ -67,6 +67,28 @@ def composite_reg_img(bg, fg, fg_mask, bw_mode=False, device="cuda"):
     return _result(out, as_numpy)
 
 
+_maps_cache = {}  # (matrix bytes, device) -> (device inverse maps, H_world2img_cam): a camera's calibration is static
+
+
+def _composite_maps(H_world2bev, H_img2world_fix, K, RT, device):
+    """The two inverse maps of compo.py:37-44 as one (2, 3, 3) device tensor, and H_world2img_cam (returned to the caller like
+    the reference does).  Cached by value: per call this is four small tobytes() instead of an inversion and an upload."""
+    mats = [np.ascontiguousarray(m, dtype=np.float64) for m in (H_world2bev, H_img2world_fix, K, RT)]
+    key = (b"".join(m.tobytes() for m in mats), tuple(m.shape for m in mats), str(device))
+    hit = _maps_cache.get(key)
+    if hit is None:
+        H_world2bev, H_img2world_fix, K, RT = mats
+        H_img2bev_fix = H_world2bev.dot(H_img2world_fix)
+        H_world2img_cam = homo_from_KRt(K, Rt_homo=RT)
+        H_img2bev_cam = H_world2bev.dot(np.linalg.inv(H_world2img_cam))
+        if len(_maps_cache) >= 64:
+            _maps_cache.clear()
+        hit = _maps_cache[key] = (device_inverse(np.stack([H_img2bev_fix, H_img2bev_cam]), device), H_world2img_cam)
+    elif hit[0].is_cuda:
+        hit[0].record_stream(torch.cuda.current_stream(hit[0].device))
+    return hit[0], hit[1].copy()
+
+
 def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_size, y_size, bw_mode=False, device="cuda"):
     """Returns (compo, H_world2img_cam) like the reference (compo.py:26-49): compo is (y_size, x_size, C) uint8."""
     as_numpy = not any(isinstance(x, torch.Tensor) for x in (bg, fg, fg_mask))
@@ -75,11 +97,7 @@ def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_si
         raise ValueError("fg and fg_mask must have one shape, and bg their channel count")
     if bw_mode:
         fg = gray_bgr(fg)
-    H_world2bev = np.asarray(H_world2bev, dtype=np.float64)
-    H_img2bev_fix = H_world2bev.dot(np.asarray(H_img2world_fix, dtype=np.float64))
-    H_world2img_cam = homo_from_KRt(np.asarray(K), Rt_homo=np.asarray(RT))
-    H_img2bev_cam = H_world2bev.dot(np.linalg.inv(H_world2img_cam))
-    minv = device_inverse(np.stack([H_img2bev_fix, H_img2bev_cam]), bg.device)  # the two inverse maps, one upload
+    minv, H_world2img_cam = _composite_maps(H_world2bev, H_img2world_fix, K, RT, bg.device)
     C = bg.shape[2]
     out = torch.empty((int(y_size), int(x_size), C), dtype=torch.uint8, device=bg.device)
     stream = torch.cuda.current_stream(bg.device).cuda_stream

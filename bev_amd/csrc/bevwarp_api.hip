@@ -160,10 +160,10 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     while (a.tile_h > rows_per_pass() && per_row_of_tiles * ((dst_h + a.tile_h - 1) / a.tile_h) < resident) a.tile_h /= 2;
     if (dtype == BEVWARP_U8 && per_row_of_tiles * ((dst_h + 23) / 24) >= 2 * resident) a.tile_h = 24;
 #ifdef BEVWARP_TILE_H  // experiments only
-#if BEVWARP_TILE_H > 64
-#error "tiles of at most 64 rows: a wave keeps one flag bit per pass"
+#if BEVWARP_TILE_H > 24
+#error "tiles of at most 24 rows (8-bit) / 16 rows (float): a wave keeps one LDS row per pass until the tile's stores"
 #endif
-    a.tile_h = BEVWARP_TILE_H;
+    a.tile_h = (dtype == BEVWARP_U8 || BEVWARP_TILE_H <= 16) ? BEVWARP_TILE_H : 16;
 #endif
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;

@@ -365,7 +365,14 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     constexpr int TRW = 64 * PPL * (sizeof(T) == 1 ? 1 : C);  // dwords of a wave's transposition row
     static_assert(!RS4 || kAligned, "RS4 only qualifies the aligned-window variant");
     static_assert(NSRC == 1 || (NSRC == 3 && sizeof(T) == 1 && INTERP == kLinear && !PLANAR), "the composite is three 8-bit bilinear warps");
-    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][TRW];
+    // Deferred stores (plain kernel): a wave keeps the pixels of ALL its passes over the tile in LDS, one transposition row per
+    // pass, and writes them to memory after its last pass.  vmcnt retires in issue order, loads and stores alike, so a store
+    // issued in pass n sits in front of the loads of pass n + 1 and their s_waitcnt cannot be satisfied before the store has
+    // been acknowledged by the memory system: with either kind of access alone the kernel runs at its ALU time, with both it
+    // loses 13 us of 75 (ablations: profiles/r03_tables.txt).  Stored at the end of the tile, nothing waits behind them.
+    // (composite: one row, its passes go to the LDS tiles at once.)
+    constexpr int kRowsLds = NSRC > 1 ? 1 : (sizeof(T) == 1 ? 6 : 4);  // passes of a wave over the tallest tile (24 / 16 rows)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][kRowsLds][TRW];
     // (composite only) the warped tiles, one packed pixel per dword: [source][row of the tile][pixel]
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[NSRC > 1 ? NSRC * kCompositeRows * TW : 4];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
@@ -636,7 +643,10 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         }
     };
 
-    uint32_t* wtr = &s_tr[wave_all][0];
+    uint32_t* const wtr0 = &s_tr[wave_all][0][0];
+    uint32_t* wtr = wtr0;  // the LDS row of the pass being blended / read back
+    constexpr bool kDefer = NSRC == 1;
+    auto lds_row = [&](int k) __attribute__((always_inline)) { wtr = kDefer ? wtr0 + k * TRW : wtr0; };
     // blend one pixel from its taps -- w0 / w1 = the LOADB bytes of the upper / lower tap row starting AT the left tap -- into
     // the wave's LDS row (pixel 64 j + lane of the segment)
     auto blend_put = [&](int j, const uint32_t (&w0)[NEED], const uint32_t (&w1)[NEED], uint32_t fx, uint32_t fy) __attribute__((always_inline)) {
@@ -674,11 +684,13 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             const uint32_t fx = S1[j] >> 27, fy = S2[j] >> 27;  // (bilinear only)
             uint32_t w0[NEED], w1[NEED];
             if constexpr (kAligned) {
-                const uint32_t sh0 = S0[j] << 3, sh1 = RS4 ? sh0 : (S0[j] + rs32) << 3;  // funnel-shift amounts (v_alignbit reads bits 4:0)
+                // funnel shift by the window's byte phase: v_alignbyte_b32 shifts by 8 * S2[1:0] on gfx950 (tools/probe_alignbyte.hip:
+                // the ISA manuals disagree on [1:0] vs [4:0]), so the byte offset itself is the shift operand
+                const uint32_t sh0 = S0[j], sh1 = RS4 ? sh0 : S0[j] + rs32;
 #pragma unroll
                 for (int k = 0; k < NEED; k++) {
-                    w0[k] = __builtin_amdgcn_alignbit(t0[j].w[k + 1], t0[j].w[k], sh0);
-                    w1[k] = __builtin_amdgcn_alignbit(t1[j].w[k + 1], t1[j].w[k], sh1);
+                    w0[k] = __builtin_amdgcn_alignbyte(t0[j].w[k + 1], t0[j].w[k], sh0);
+                    w1[k] = __builtin_amdgcn_alignbyte(t1[j].w[k + 1], t1[j].w[k], sh1);
                 }
             } else {
 #pragma unroll
@@ -1047,15 +1059,17 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             n_blended++;
         };
         bool more;
+        int k_blend = 0;  // index of the pass being blended (its LDS row when stores are deferred)
         auto step = [&](uint32_t (&C0)[PPL], uint32_t (&C1)[PPL], uint32_t (&C2)[PPL], uint32_t (&N0)[PPL], uint32_t (&N1)[PPL], uint32_t (&N2)[PPL])
                         __attribute__((always_inline)) {
-            read_back(out);  // p_cur's pixels (written a step ago: no LDS latency on the path)
+            if constexpr (!kDefer) read_back(out);  // p_cur's pixels (written a step ago: no LDS latency on the path)
             issue_s(kFast, C0, u0, u1);
             const Pass p_st = p_cur;
             p_cur = p_nxt;
             more = next_pass(own, p_nxt);
             if (more) coords_f(p_nxt, N0, N1, N2);
-            store_s(own, pass_x(p_st), p_st.y, out);  // behind the loads: vmcnt retires in issue order
+            if constexpr (!kDefer) store_s(own, pass_x(p_st), p_st.y, out);  // behind the loads: vmcnt retires in issue order
+            lds_row(++k_blend);
             finish_s(C0, C1, C2, u0, u1);
             note_ties(C1, C2);
         };
@@ -1064,6 +1078,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         p_cur = p_nxt;
         more = next_pass(own, p_nxt);
         if (more) coords_f(p_nxt, B0, B1, B2);
+        lds_row(0);
         finish_s(A0, A1, A2, u0, u1);
         note_ties(A1, A2);
         while (more) {  // (two steps per trip: the states swap roles instead of being copied)
@@ -1071,19 +1086,34 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             if (!more) break;
             step(A0, A1, A2, B0, B1, B2);
         }
-        read_back(out);
-        store_s(own, pass_x(p_cur), p_cur.y, out);
+        if constexpr (!kDefer) {
+            read_back(out);
+            store_s(own, pass_x(p_cur), p_cur.y, out);
+        }
         if (__builtin_expect(tie_passes != 0, 0)) {  // redo the flagged passes: every pixel by the exact chain and the generic sampler
             Pass p;
             first_pass(own, p);
-            int k = n_blended - 1;
+            int k = n_blended - 1, kr = 0;
             do {
                 if ((tie_passes >> k) & 1ull) {
+                    lds_row(kr);
                     slow_s(own, InTail{}, pass_x(p), p.y);
-                    read_back(out);
-                    store_s(own, pass_x(p), p.y, out);
+                    if constexpr (!kDefer) {
+                        read_back(out);
+                        store_s(own, pass_x(p), p.y, out);
+                    }
                 }
-                k--;
+                k--, kr++;
+            } while (next_pass(own, p));
+        }
+        if constexpr (kDefer) {  // every pass of this wave, LDS -> memory: the stores trail the tile's last load
+            Pass p;
+            first_pass(own, p);
+            int kr = 0;
+            do {
+                lds_row(kr++);
+                read_back(out);
+                store_s(own, pass_x(p), p.y, out);
             } while (next_pass(own, p));
         }
     };
@@ -1100,11 +1130,13 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     auto edge_tile = [&](auto own) __attribute__((always_inline)) {
         Pass p_cur, p_nxt;
         if (!first_pass(own, p_nxt)) return;
+        int k_blend = 0;
         int cls_c = coords_s(own, p_nxt.strip, p_nxt.y, A0, A1, A2), cls_n = kSlow;
         issue_s(cls_c, A0, u0, u1);
         p_cur = p_nxt;
         bool more = next_pass(own, p_nxt);
         if (more) cls_n = coords_s(own, p_nxt.strip, p_nxt.y, B0, B1, B2);
+        lds_row(0);
         finish_any(own, cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
         while (more) {
 #pragma unroll
@@ -1114,17 +1146,29 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
                 A2[j] = B2[j];
             }
             cls_c = cls_n;
-            read_back(out);
+            if constexpr (!kDefer) read_back(out);
             issue_s(cls_c, A0, u0, u1);
             const Pass p_st = p_cur;
             p_cur = p_nxt;
             more = next_pass(own, p_nxt);
             if (more) cls_n = coords_s(own, p_nxt.strip, p_nxt.y, B0, B1, B2);  // overlaps with the loads in flight
-            store_s(own, pass_x(p_st), p_st.y, out);
+            if constexpr (!kDefer) store_s(own, pass_x(p_st), p_st.y, out);
+            lds_row(++k_blend);
             finish_any(own, cls_c, pass_x(p_cur), p_cur.y, A0, A1, A2, u0, u1);
         }
-        read_back(out);
-        store_s(own, pass_x(p_cur), p_cur.y, out);
+        if constexpr (!kDefer) {
+            read_back(out);
+            store_s(own, pass_x(p_cur), p_cur.y, out);
+        } else {
+            Pass p;
+            first_pass(own, p);
+            int kr = 0;
+            do {
+                lds_row(kr++);
+                read_back(out);
+                store_s(own, pass_x(p), p.y, out);
+            } while (next_pass(own, p));
+        }
     };
     if (tile_slanted)
         edge_tile(PatSeg{});
