@@ -167,7 +167,8 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     elif src.dim() != 4:
         raise ValueError("src must be (B,H,W,C), (H,W,C) or (H,W)")
     B, H, W, C = s4.shape
-    if s4.stride(3) != 1 or s4.stride(2) != C:
+    copied = s4.stride(3) != 1 or s4.stride(2) != C
+    if copied:
         s4 = s4.contiguous()
     dw, dh = int(dsize[0]), int(dsize[1])
     esz = s4.element_size()
@@ -189,7 +190,7 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     with torch.cuda.device(s4.device):
         st = fn(*args, ctypes.c_void_p(stream))
     _lib.check(st)
-    if key is not None and s4 is src:  # validated and launched: the next call with these very buffers skips the checks
+    if key is not None and not copied:  # validated and launched: the next call with these very buffers skips the checks
         if len(_plans) >= _PLANS_MAX:
             _plans.clear()
         _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device())

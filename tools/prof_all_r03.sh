@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round-3 profile set (GPU box): kernel-trace stats + SQ / FETCH / WRITE / TCC passes for the six benchmarked workloads of
+# configs[1], then profiles/pmc_traffic.json is rebuilt from them by tools/make_traffic.py r03 (on the build side).
+for spec in "u8_linear --dtype u8" "f32_linear --dtype f32" "u8_nearest --dtype u8 --interp nearest" "u8_brno --dtype u8 --homography brno" \
+            "f32_brno --dtype f32 --homography brno" "u8_nearest_brno --dtype u8 --interp nearest --homography brno"; do
+  set -- $spec
+  tag=$1; shift
+  bash tools/prof.sh $tag "$@" > gpurun_out/prof_$tag.log 2>&1
+  echo "== $tag"; grep -E "warp_rows|FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU |SQ_ACTIVE_INST_VALU" gpurun_out/prof_$tag/summary.txt | cut -c1-140
+done
