@@ -931,7 +931,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // the tile maps into the convex quadrilateral of their images: every row is FAST and the loop needs no row classes --
     // no end-pixel read-out, no scalar decisions, row terms advanced by one addition each.
     // -- the tile's four corner pixels decide how it is processed
-    bool tile_in, tile_slanted, tile_out;
+    bool tile_in, tile_slanted, tile_out, tile_affine;
     {
         const int ck = lane & 3;
         const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)((ck & 2) ? y_last : y0);
@@ -969,6 +969,25 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         // (Single-channel float is the exception: its 32 x 2 patches lose to row segments up to ~20 degrees: 45.)
         constexpr float kSlantThr = sizeof(T) == 4 && C == 1 ? 45.0f : 45.0f / (float)PBs;
         tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) > kSlantThr * 4096.0f * (float)(kStrips * kStrips * kStrips);
+        // Row-affine tiles.  Taking W and Y at a segment's first pixel for all TW of them leaves out m6 x in W and m3 x in Y: in
+        // the fixed-point units of the chain (source pixels x 2^32) at most
+        //     E = TW (|m3| 2^32 r + |m6| r^2 max(|X|, |Y|))        r = 1 / min |W|, X / Y the numerators, all over the tile's corners
+        // (W of one sign is linear, so its extremes are at the corners; the numerators are affine too).  The tie window leaves
+        // room: the chain itself is within 2^-21.9 output units of the reference for every coordinate the binade admits, the
+        // window is 2^-19, so E <= 2^-21 units keeps every pixel outside a window on the reference's side of its rounding boundary.
+        // Exactly zero for M3 = M6 = 0; ~1e-5 for a keystone whose matrix came out of a least-squares fit.
+        {
+            const double aw = fabs(cW), ax = fabs(__builtin_fma(RX, cdy, CX) + (m0 * kTwo32) * cdx), ay = fabs(__builtin_fma(RY, cdy, CY) + (m3 * kTwo32) * cdx);
+            auto max4 = [](double v) {
+                v = fmax(v, __shfl_xor(v, 1));
+                return fmax(v, __shfl_xor(v, 2));
+            };
+            const double w_min = -max4(-aw), n_max = max4(fmax(ax, ay));
+            const double rr = 1.0 / w_min;
+            const double E = (double)TW * (fabs(m3) * kTwo32 * rr + fabs(m6) * rr * rr * n_max);
+            constexpr double kUnit = INTERP == kLinear ? 134217728.0 /* 2^27 */ : kTwo32;
+            tile_affine = __builtin_amdgcn_readfirstlane((int)(E <= kUnit * (1.0 / 2097152.0) /* 2^-21 */)) != 0;
+        }
     }
     // -- the passes of this wave over the tile, in order.
     //   row segments: rows y0 + w + 4 i (neighbouring rows share source lines and run at the same time)
@@ -1023,8 +1042,16 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // at worst -- still inside the frame, the tile test keeps a pixel of margin for exactly this), a flag is shifted into a
     // scalar mask, and flagged passes (rare) are redone whole by the exact chain after the loop.  With the exact chain out
     // of the loop its state fits 128 VGPRs: four waves per SIMD instead of three (-12 %: DESIGN.md section 6.2).
-    auto interior = [&](auto own) __attribute__((always_inline)) {
+    // ROW-AFFINE tiles (`row_affine` tag; row segments only).  When the source row and the perspective divide do not depend on the
+    // destination column -- inverse matrix with M3 = M6 = 0: the rectification / inverse-perspective form, every keystone, every
+    // scale + shift; judged per tile with the tolerance derived at `tile_affine` -- a row segment needs ONE reciprocal and ONE Y
+    // coordinate per pass, the same in every lane: X = (UX + x M0) r is one add and one FMA per pixel, the tap row's byte offset is
+    // a scalar, fy and the Y tie flag are wave-uniform.  18 float64 instructions per 256-pixel row instead of 38, 4 offset
+    // instructions instead of 12.
+    auto interior = [&](auto own, auto row_affine) __attribute__((always_inline)) {
         constexpr bool kBlk = decltype(own)::blk;
+        constexpr bool kAff = decltype(row_affine)::value;
+        static_assert(!kAff || !kBlk, "row-affine passes are row segments");
         Pass p_cur, p_nxt;  // p_cur: the pass whose pixels sit in the LDS row; p_nxt: the pass whose coordinates are in the C state
         if (!first_pass(own, p_nxt)) return;
         // row terms of the pass the coordinate stage is at; a row segment's advance by one addition per pass
@@ -1033,6 +1060,26 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         if (!kBlk) UX = __builtin_fma(RX, (double)p_nxt.y, CX), UY = __builtin_fma(RY, (double)p_nxt.y, CY), UW = __builtin_fma(RW, (double)p_nxt.y, CW);
         auto coords_f = [&](const Pass& p, uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
             uint32_t hx[PPL], lx[PPL], hy[PPL], ly[PPL], wf_, wl_;
+            if constexpr (kAff) {
+                // W, 1 / W and Y at the segment's first pixel stand for the whole segment (tile_affine bounds what that ignores)
+                const double r = rcp_newton(UW);
+                const double ty_ = __builtin_fma(UY, r, F::kMagic);
+                const uint32_t hyu = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(ty_)), lyu = (uint32_t)__builtin_amdgcn_readfirstlane(__double2loint(ty_));
+                const uint32_t row_off = (hyu & 0xffffffu) * rs32 + kOff;  // scalar; the low 24 bits like v_mul_u32_u24 (kOff carries their bias)
+                double Xn = UX + cx0;
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    const double tx_ = __builtin_fma(Xn, r, F::kMagic);
+                    S0[j] = __umul24((uint32_t)__double2hiint(tx_), (uint32_t)PBs) + row_off;
+                    S1[j] = (uint32_t)__double2loint(tx_);
+                    S2[j] = lyu;
+                    if (j + 1 < PPL) Xn += DX;
+                }
+                UX += SX;
+                UY += SY;
+                UW += SW;
+                return;
+            }
             if constexpr (kBlk) {
                 set_strip(p.strip);
                 chain(own, p.y, hx, lx, hy, ly, wf_, wl_);
@@ -1120,10 +1167,14 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // (the branch hints keep the common path -- interior tile, row segments -- the fall-through: with the patch code in the
     // kernel its layout otherwise costs unturned footprints 3 %)
     if (__builtin_expect(tile_in, 1)) {
-        if (__builtin_expect(!tile_slanted, 1))
-            interior(RowSeg{});
-        else
-            interior(PatSeg{});
+        if (__builtin_expect(!tile_slanted, 1)) {
+            if (tile_affine)
+                interior(RowSeg{}, std::true_type{});
+            else
+                interior(RowSeg{}, std::false_type{});
+        } else {
+            interior(PatSeg{}, std::false_type{});
+        }
         return;
     }
     // -- the frame's edge crosses the tile (or W changes sign in it): blocks with a class each, the same pipeline

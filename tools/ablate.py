@@ -9,6 +9,7 @@ Each spec patches a COPY of warp_kernels.hip:
     noblend   finish_s xors the taps instead of blending
     stsmall   stores go to a few KB per frame (no HBM write traffic)
     ldsmall   taps come from the first 64 KB of the frame (cache hits)
+    ldx2 / ldx1   (timing only) the aligned 12-byte tap windows fetched as 8 / 4 bytes: the texture path's cost per returned byte
     notie     no tie-window test in the coordinate chain
     ntload    float taps through non-temporal loads
     noedge    EDGE blocks cost what OUT blocks cost
@@ -44,6 +45,10 @@ def patch(src, spec):
     elif spec == "stsmall":
         rep("            uint8_t* d = dframe + (int64_t)(y + st_row) * a.dst_rs + (int64_t)st_x * C;\n",
             "            uint8_t* d = dframe + (int64_t)((y + st_row) & 7) * a.dst_rs + (int64_t)(st_x & 255) * C;\n")
+    elif spec in ("ldx2", "ldx1"):  # timing only (wrong pixels): the aligned tap windows fetched as 8 / 4 bytes instead of 12
+        n = 8 if spec == "ldx2" else 4
+        rep("                const uint32_t offa = off & ~3u;\n                __builtin_memcpy(&t0[j], b0 + offa, WINB);\n                __builtin_memcpy(&t1[j], b1 + offa, WINB);\n",
+            "                const uint32_t offa = off & ~3u;\n                __builtin_memcpy(&t0[j], b0 + offa, %d);\n                __builtin_memcpy(&t1[j], b1 + offa, %d);\n" % (n, n))
     elif spec == "ldsmall":
         rep("            const uint32_t off = S0[j];\n", "            const uint32_t off = S0[j] & 0xffffu;\n")
     elif spec == "ntload":  # float taps through non-temporal loads (streaming probe: nt loads + nt stores is the box's best mix)
