@@ -345,3 +345,36 @@ def test_random_homographies_all_formats(W, seed):
             exp = co.warp_perspective(frames[i], Ms[i], (dw, dh), interp, border_value=0 if border is None else border)
             np.testing.assert_array_equal(got[i].reshape(exp.shape), exp, err_msg="seed %d case %d frame %d: %dx%d -> %dx%d c=%d %s interp=%d" % (
                 seed, case, i, sw, sh, dw, dh, c, np.dtype(dtype).name, interp))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_row_affine_tiles_and_their_tolerance(W, dtype, interp):
+    """Interior tiles whose source row and divide do not depend on the destination column take one reciprocal and one Y
+    coordinate per row segment (warp_kernels.hip, `tile_affine`).  Exact members of the class (M3 = M6 = 0: scale + shift,
+    keystone), members up to floating-point noise, and matrices that cross the tolerance from below and from above -- all must
+    equal the oracle; ties on X, on the uniform Y, and on both."""
+    sw, sh, dw, dh = 700, 420, 512, 96
+    src = wl.frame(31, sh, sw, dtype)
+
+    def both_inv(M):  # cv2.WARP_INVERSE_MAP: M is the dst -> src map itself, so its entries are exactly what the kernel sees
+        np.testing.assert_array_equal(run_gpu(W, src, M, (dw, dh), interp | 16), co.warp_perspective(src, M, (dw, dh), interp, m_is_inverse=True))
+
+    base = np.array([[1.25, 0.0, 20.0], [0.0, 1.5, 30.0], [0.0, 0.004, 1.0]])  # keystone form: Y / W and W depend on y only
+    both_inv(base)
+    both_inv(np.array([[1.0, 0.0, 7.0], [0.0, 1.0, 5.0], [0.0, 0.0, 1.0]]))          # integer shift: ties everywhere
+    both_inv(np.array([[2.0, 0.0, 3.5], [0.0, 1.0, 9.0 + 1 / 64], [0.0, 0.0, 1.0]]))   # X and (uniform) Y on rounding ties
+    both_inv(np.array([[1.0, 0.0, 1 / 64], [0.0, 3.0, 1.0 / 3.0], [0.0, 0.0, 2.0]]))
+    for eps in (1e-18, 1e-15, 1e-14, 3e-14, 1e-13, 1e-11, 1e-8, 1e-5):  # the tolerance sits near 3e-14 for these sizes
+        for (i, j) in ((2, 0), (1, 0)):
+            M = base.copy()
+            M[i, j] = eps if i == 2 else eps * 300.0
+            both_inv(M)
+            M[i, j] = -M[i, j]
+            both_inv(M)
+    # a least-squares keystone (the benchmark's matrix) and its jittered frames, batched
+    Ms = np.stack([wl.jitter_H(wl.keystone_H(sw, sh, dw, dh), g) for g in range(4)])
+    frames = np.stack([wl.frame(32 + g, sh, sw, dtype) for g in range(4)])
+    got = W.warp_perspective(torch.from_numpy(frames).cuda(), Ms, (dw, dh), flags=interp).cpu().numpy()
+    for g in range(4):
+        np.testing.assert_array_equal(got[g], co.warp_perspective(frames[g], Ms[g], (dw, dh), interp))
