@@ -49,6 +49,20 @@ def patch(src, spec):
         n = 8 if spec == "ldx2" else 4
         rep("                const uint32_t offa = off & ~3u;\n                __builtin_memcpy(&t0[j], b0 + offa, WINB);\n                __builtin_memcpy(&t1[j], b1 + offa, WINB);\n",
             "                const uint32_t offa = off & ~3u;\n                __builtin_memcpy(&t0[j], b0 + offa, %d);\n                __builtin_memcpy(&t1[j], b1 + offa, %d);\n" % (n, n))
+    elif spec in ("cohload", "cohload2"):  # timing only: the 8 window gathers of a pass replaced by coalesced 16-byte loads of the source
+        # row span the pass starts at (1.5 KB of ONE row: what a wave that keeps the other tap row staged would fetch; cohload2: both rows)
+        both_rows = "1" if spec == "cohload2" else "0"
+        rep("#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n",
+            "        if (f && kAligned) {\n"
+            "            const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)S0[0]) & ~15u;\n"
+            "            typedef uint32_t q4 __attribute__((ext_vector_type(4)));\n"
+            "            q4 r0 = *reinterpret_cast<const q4*>(b0 + start + lane * 16), r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};\n"
+            "            if (lane < 32) r1 = *reinterpret_cast<const q4*>(b0 + start + 1024 + lane * 16);\n"
+            "            if (" + both_rows + ") { r2 = *reinterpret_cast<const q4*>(b1 + start + lane * 16); if (lane < 32) r3 = *reinterpret_cast<const q4*>(b1 + start + 1024 + lane * 16); }\n"
+            "            for (int j = 0; j < PPL; j++)\n"
+            "                for (int k = 0; k < WINB / 4; k++) t0[j].w[k] = S0[j] * (k + 3) + r0[k] + r1[(k + j) & 3] + r2[k], t1[j].w[k] = S0[j] ^ (0x9e3779b9u * (k + 1)) ^ r0[3] ^ r3[j & 3];\n"
+            "            return;\n        }\n"
+            "#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n")
     elif spec == "ldsmall":
         rep("            const uint32_t off = S0[j];\n", "            const uint32_t off = S0[j] & 0xffffu;\n")
     elif spec == "ntload":  # float taps through non-temporal loads (streaming probe: nt loads + nt stores is the box's best mix)
