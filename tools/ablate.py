@@ -63,6 +63,22 @@ def patch(src, spec):
             "                for (int k = 0; k < WINB / 4; k++) t0[j].w[k] = S0[j] * (k + 3) + r0[k] + r1[(k + j) & 3] + r2[k], t1[j].w[k] = S0[j] ^ (0x9e3779b9u * (k + 1)) ^ r0[3] ^ r3[j & 3];\n"
             "            return;\n        }\n"
             "#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n")
+    elif spec in ("cohf32", "cohf32b"):  # timing only, float RGB: the 16 tap gathers of a pass replaced by coalesced loads of 2.75 KB of ONE source row (b: both rows)
+        both_rows = "1" if spec == "cohf32b" else "0"
+        rep("#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n",
+            "        if (f && sizeof(T) == 4 && C == 3 && INTERP == kLinear) {\n"
+            "            const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)S0[0]) & ~15u;\n"
+            "            typedef uint32_t q4 __attribute__((ext_vector_type(4)));\n"
+            "            q4 r[6];\n"
+            "            for (int i = 0; i < 6; i++) r[i] = q4{0, 0, 0, 0};\n"
+            "            r[0] = *reinterpret_cast<const q4*>(b0 + start + lane * 16);\n"
+            "            r[1] = *reinterpret_cast<const q4*>(b0 + start + 1024 + lane * 16);\n"
+            "            if (lane < 48) r[2] = *reinterpret_cast<const q4*>(b0 + start + 2048 + lane * 16);\n"
+            "            if (" + both_rows + ") { r[3] = *reinterpret_cast<const q4*>(b1 + start + lane * 16); r[4] = *reinterpret_cast<const q4*>(b1 + start + 1024 + lane * 16); if (lane < 48) r[5] = *reinterpret_cast<const q4*>(b1 + start + 2048 + lane * 16); }\n"
+            "            for (int j = 0; j < PPL; j++)\n"
+            "                for (int k = 0; k < LOADB / 4; k++) t0[j].w[k] = r[k % 3][k & 3] ^ r[(k + j) % 3][(k + 1) & 3], t1[j].w[k] = r[3 + k % 3][k & 3] ^ r[0][(k + j) & 3];\n"
+            "            return;\n        }\n"
+            "#pragma unroll\n        for (int j = 0; j < PPL; j++) {\n            const uint32_t off = S0[j];\n")
     elif spec == "ldsmall":
         rep("            const uint32_t off = S0[j];\n", "            const uint32_t off = S0[j] & 0xffffu;\n")
     elif spec == "ntload":  # float taps through non-temporal loads (streaming probe: nt loads + nt stores is the box's best mix)
