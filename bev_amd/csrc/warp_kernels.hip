@@ -372,18 +372,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // loses 13 us of 75 (ablations: profiles/r03_tables.txt).  Stored at the end of the tile, nothing waits behind them.
     // (composite: one row, its passes go to the LDS tiles at once.)
     constexpr int kRowsLds = NSRC > 1 ? 1 : (sizeof(T) == 1 ? 6 : 4);  // passes of a wave over the tallest tile (24 / 16 rows)
-    // STAGED tiles (interior_staged below): a wave that owns CONSECUTIVE rows of a row-affine tile keeps the two source rows of
-    // its pass in an LDS ring of two slots and fetches the one new row a pass needs with coalesced 16-byte LDS-DMA loads.
-#ifndef BEVWARP_STAGE
-#define BEVWARP_STAGE 3  // experiments: bit 0 stages float tiles, bit 1 8-bit tiles
-#endif
-    constexpr bool kStageable = NSRC == 1 && C == 3 && INTERP == kLinear && (sizeof(T) == 4 ? (BEVWARP_STAGE & 1) != 0 : (RS4 && (BEVWARP_STAGE & 2) != 0));
-    constexpr int kSlot = sizeof(T) == 1 ? 1536 : 2816;  // bytes of one staged source-row span (256 px x 1.9 x 3 B / 128 px x 1.8 x 12 B)
-    constexpr int kStageRows = sizeof(T) == 1 ? kRowsLds : 1;  // output rows the staged path keeps (8-bit: deferred stores; float: one)
-    constexpr int kRingOff = kStageRows * TRW * 4;
-    constexpr int kSlots = sizeof(T) == 1 ? 2 : 3;       // float: a third slot takes the row of the pass AFTER next, a whole step ahead
-    constexpr int kWaveBytes = kStageable && kRingOff + kSlots * kSlot > kRowsLds * TRW * 4 ? kRingOff + kSlots * kSlot : kRowsLds * TRW * 4;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][kWaveBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][kRowsLds][TRW];
     // (composite only) the warped tiles, one packed pixel per dword: [source][row of the tile][pixel]
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[NSRC > 1 ? NSRC * kCompositeRows * TW : 4];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
@@ -654,7 +643,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         }
     };
 
-    uint32_t* const wtr0 = &s_tr[wave_all][0];
+    uint32_t* const wtr0 = &s_tr[wave_all][0][0];
     uint32_t* wtr = wtr0;  // the LDS row of the pass being blended / read back
     constexpr bool kDefer = NSRC == 1;
     auto lds_row = [&](int k) __attribute__((always_inline)) { wtr = kDefer ? wtr0 + k * TRW : wtr0; };
@@ -942,8 +931,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // the tile maps into the convex quadrilateral of their images: every row is FAST and the loop needs no row classes --
     // no end-pixel read-out, no scalar decisions, row terms advanced by one addition each.
     // -- the tile's four corner pixels decide how it is processed
-    bool tile_in, tile_slanted, tile_out, tile_affine, tile_stage = false;
-    uint32_t span_start = 0, span_len = 0;  // staged tiles: the bytes [span_start, span_start + span_len) of a source row hold every tap of the tile
+    bool tile_in, tile_slanted, tile_out, tile_affine;
     {
         const int ck = lane & 3;
         const double cdx = (ck & 1) ? (double)(TW - 1) : 0.0, cdy = (double)((ck & 2) ? y_last : y0);
@@ -999,18 +987,6 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             const double E = (double)TW * (fabs(m3) * kTwo32 * rr + fabs(m6) * rr * rr * n_max);
             constexpr double kUnit = INTERP == kLinear ? 134217728.0 /* 2^27 */ : kTwo32;
             tile_affine = __builtin_amdgcn_readfirstlane((int)(E <= kUnit * (1.0 / 2097152.0) /* 2^-21 */)) != 0;
-        }
-        if constexpr (kStageable) {
-            // the tile maps into the quadrilateral of its corners' images: source columns min..max of the four (one pixel of slack
-            // each side for the unit a fast coordinate may be off), taps reach one pixel further, aligned windows 12 bytes
-            int lo = min(csx, __shfl_xor(csx, 1)), hi = max(csx, __shfl_xor(csx, 1));
-            lo = min(lo, __shfl_xor(lo, 2)), hi = max(hi, __shfl_xor(hi, 2));
-            const int b0s = max(0, (lo - 1) * PBs) & ~15, b1s = (hi + 3) * PBs + (kAligned ? 12 : 0);
-            const int len = (b1s - b0s + 15) & ~15;
-            const bool ok = len <= kSlot && b0s + len <= src_w * PBs && ((reinterpret_cast<uintptr_t>(frame) | (uintptr_t)rs32) & 3u) == 0;
-            tile_stage = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-            span_start = (uint32_t)__builtin_amdgcn_readfirstlane(b0s);
-            span_len = (uint32_t)__builtin_amdgcn_readfirstlane(len);
         }
     }
     // -- the passes of this wave over the tile, in order.
@@ -1188,173 +1164,14 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             } while (next_pass(own, p));
         }
     };
-    // -- STAGED row-affine tiles.  The wave owns the tile's rows ya..yb (consecutive); a pass needs source rows sy and sy + 1, the
-    // same for all its pixels; slot r & 1 of the ring holds row r.  Per pass: wait for the DMA issued a pass ago -> read the taps
-    // out of the two slots (aligned dwords) -> once they are in registers (lgkmcnt(0)) issue the DMA of whatever row the NEXT pass
-    // lacks, usually one -> blend.  A source row is fetched once per wave, in 1-KB coalesced pieces, instead of once per tap pair.
-    auto interior_staged = [&]() __attribute__((always_inline)) {
-        if constexpr (kStageable) {
-            typedef __attribute__((address_space(1))) const void* gptr_t;
-            typedef __attribute__((address_space(3))) void* lptr_t;
-            const int rows_t = y_last - y0 + 1, rpw = (rows_t + kWaves - 1) / kWaves;
-            const int ya = y0 + wave * rpw, yb = min(ya + rpw - 1, y_last);
-            if (ya > yb) return;
-            uint8_t* const ring = reinterpret_cast<uint8_t*>(wtr0) + kRingOff;
-            double UX = __builtin_fma(RX, (double)ya, CX), UY = __builtin_fma(RY, (double)ya, CY), UW = __builtin_fma(RW, (double)ya, CW);
-            const uint32_t kXs = 0u - span_start - 0x380000u * (uint32_t)PBs;  // byte of a tap inside a slot = (hx & 0xffffff) * PBs + kXs
-            int have0 = -1, have1 = -1, have2 = -1;  // the source rows the slots hold (slot of row r: r mod kSlots)
-            const int nch = (int)((span_len + 1023u) >> 10);  // DMA instructions per row: wave-uniform, so that vmcnt can be counted
-            auto slot_of = [](int r) { return (int)((uint32_t)r % (uint32_t)kSlots); };
-            auto dma_row = [&](int r) __attribute__((always_inline)) {
-                const int sl = slot_of(r);
-                const uint8_t* g = frame + (uint32_t)r * rs32 + span_start + lane * 16;
-                uint8_t* l = ring + sl * kSlot;
-                // exactly nch instructions: piece c has active lanes for every c < nch, and an instruction is issued when any lane is active
-#pragma unroll
-                for (int c = 0; c < (kSlot + 1023) / 1024; c++)
-                    if ((uint32_t)(c * 1024 + lane * 16) < span_len) __builtin_amdgcn_global_load_lds((gptr_t)(g + c * 1024), (lptr_t)(l + c * 1024), 16, 0, 0);
-                if (sl == 0)
-                    have0 = r;
-                else if (sl == 1)
-                    have1 = r;
-                else
-                    have2 = r;
-            };
-            auto have_of = [&](int sl) { return sl == 0 ? have0 : (sl == 1 ? have1 : have2); };
-            auto ensure = [&](int r) __attribute__((always_inline)) -> int {
-                if (have_of(slot_of(r)) == r) return 0;
-                dma_row(r);
-                return nch;
-            };
-            auto wait_dma_but = [&](int younger) __attribute__((always_inline)) {  // wait until at most `younger` vector-memory instructions are outstanding
-                switch (younger) {
-                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                }
-            };
-            // coordinates of one pass: S0 = byte of the left tap inside a slot, S1 / S2 = low dwords of tX / tY; returns the source row
-            auto coords_g = [&](uint32_t (&S0)[PPL], uint32_t (&S1)[PPL], uint32_t (&S2)[PPL]) __attribute__((always_inline)) -> int {
-                const double r = rcp_newton(UW);
-                const double ty_ = __builtin_fma(UY, r, F::kMagic);
-                const uint32_t hyu = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(ty_)), lyu = (uint32_t)__builtin_amdgcn_readfirstlane(__double2loint(ty_));
-                double Xn = UX + cx0;
-#pragma unroll
-                for (int j = 0; j < PPL; j++) {
-                    const double tx_ = __builtin_fma(Xn, r, F::kMagic);
-                    S0[j] = __umul24((uint32_t)__double2hiint(tx_), (uint32_t)PBs) + kXs;
-                    S1[j] = (uint32_t)__double2loint(tx_);
-                    S2[j] = lyu;
-                    if (j + 1 < PPL) Xn += DX;
-                }
-                UX += RX;
-                UY += RY;
-                UW += RW;
-                return (int)(hyu - kHiBias);
-            };
-            auto read_taps = [&](int sy, const uint32_t (&S0)[PPL]) __attribute__((always_inline)) {
-                const uint8_t* top = ring + slot_of(sy) * kSlot;
-                const uint8_t* bot = ring + slot_of(sy + 1) * kSlot;
-#pragma unroll
-                for (int j = 0; j < PPL; j++) {
-                    const uint32_t a = kAligned ? (S0[j] & ~3u) : S0[j];
-                    const uint32_t* pt = reinterpret_cast<const uint32_t*>(top + a);
-                    const uint32_t* pb = reinterpret_cast<const uint32_t*>(bot + a);
-#pragma unroll
-                    for (int k = 0; k < WINB / 4; k++) {
-                        u0[j].w[k] = pt[k];
-                        u1[j].w[k] = pb[k];
-                    }
-                }
-            };
-            uint64_t tie_passes = 0;
-            int n_blended = 0;
-            auto note_ties = [&](const uint32_t (&S1)[PPL], const uint32_t (&S2)[PPL]) __attribute__((always_inline)) {
-                uint32_t tie = 0xffffffffu;
-#pragma unroll
-                for (int j = 0; j < PPL; j++) tie = min(tie, min(S1[j] & F::kTieMask, S2[j] & F::kTieMask));
-                tie_passes = (tie_passes << 1) | (uint64_t)(__ballot(tie == 0) != 0ull);
-                n_blended++;
-            };
-            constexpr bool kKeep = kStageRows > 1;  // every pass keeps its LDS row until the tile's stores (8-bit)
-            int y = ya, k = 0, sy_c, sy_n = 0;
-            int n_ahead = 0;  // DMA instructions issued a step ago for the pass AFTER the one about to read: they may still be in flight
-            bool more;
-            auto step = [&](uint32_t (&C0)[PPL], uint32_t (&C1)[PPL], uint32_t (&C2)[PPL], uint32_t (&N0)[PPL], uint32_t (&N1)[PPL], uint32_t (&N2)[PPL])
-                            __attribute__((always_inline)) {
-                more = y < yb;
-                if (more) sy_n = coords_g(N0, N1, N2);
-                wait_dma_but(n_ahead);  // the rows of this pass have landed (nothing else orders a ds_read behind an LDS-DMA)
-                read_taps(sy_c, C0);
-                if constexpr (!kKeep) {
-                    if (k > 0) store_s(RowSeg{}, x0, y - 1, out);  // the previous pass, a step late: behind the wait above, a step ahead of the next
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the taps are in registers: their slots may be overwritten
-                n_ahead = 0;
-                if (more) {
-                    int demand = ensure(sy_n);
-                    demand += ensure(sy_n + 1);
-                    if constexpr (kSlots > 2) {
-                        // rows of the pass after next, predicted from this pass's step: into slots the next pass does not read
-                        const int p = 2 * sy_n - sy_c;
-                        for (int q = p; q <= p + 1; q++)
-                            if (q != sy_n && q != sy_n + 1 && q >= 0 && q < src_h && slot_of(q) != slot_of(sy_n) && slot_of(q) != slot_of(sy_n + 1)) n_ahead += ensure(q);
-                    }
-                    (void)demand;  // (rows the NEXT pass lacked were requested before the look-ahead ones: older, so the counted wait covers them)
-                }
-                lds_row(kKeep ? k : 0);
-                finish_s(C0, C1, C2, u0, u1);
-                note_ties(C1, C2);
-                if constexpr (!kKeep) read_back(out);
-                sy_c = sy_n;
-                y++, k++;
-            };
-            sy_c = coords_g(A0, A1, A2);
-            ensure(sy_c);
-            ensure(sy_c + 1);
-            do {
-                step(A0, A1, A2, B0, B1, B2);
-                if (!more) break;
-                step(B0, B1, B2, A0, A1, A2);
-            } while (more);
-            if constexpr (!kKeep) store_s(RowSeg{}, x0, yb, out);
-            if (__builtin_expect(tie_passes != 0, 0)) {  // redo the flagged passes by the exact chain and the generic sampler (from memory)
-                for (int i = 0; i < n_blended; i++) {
-                    if ((tie_passes >> (n_blended - 1 - i)) & 1ull) {
-                        lds_row(kKeep ? i : 0);
-                        slow_s(RowSeg{}, InTail{}, x0, ya + i);
-                        if constexpr (!kKeep) {
-                            read_back(out);
-                            store_s(RowSeg{}, x0, ya + i, out);
-                        }
-                    }
-                }
-            }
-            if constexpr (kKeep) {
-                for (int i = 0; i < n_blended; i++) {
-                    lds_row(i);
-                    read_back(out);
-                    store_s(RowSeg{}, x0, ya + i, out);
-                }
-            }
-        }
-    };
     // (the branch hints keep the common path -- interior tile, row segments -- the fall-through: with the patch code in the
     // kernel its layout otherwise costs unturned footprints 3 %)
     if (__builtin_expect(tile_in, 1)) {
         if (__builtin_expect(!tile_slanted, 1)) {
-            if (tile_affine) {
-                if (kStageable && tile_stage && y_last - y0 + 1 >= 3 * kWaves)  // (a wave with fewer than three rows fetches more than it reuses)
-                    interior_staged();
-                else
-                    interior(RowSeg{}, std::true_type{});
-            } else {
+            if (tile_affine)
+                interior(RowSeg{}, std::true_type{});
+            else
                 interior(RowSeg{}, std::false_type{});
-            }
         } else {
             interior(PatSeg{}, std::false_type{});
         }
