@@ -6,7 +6,11 @@ written below, and only the import / call LINES of /root/reference/vis_homo.py:1
 /root/reference/bev/tool/rbox_tracking_BrnoCompSpeed.py:1-6 are mirrored (they are the interface under test).
 
 CPU tests check the resolution (who serves which name); the `-m gpu` tests run the same scripts with a device and compare the
-pixels / IoUs with the oracle."""
+pixels / IoUs with the oracle.
+
+Two further CPU tests at the end run only where /root/reference exists (the build container; never the GPU box, and nothing of
+the reference is copied): the reference's OWN vis_homo.py, byte for byte, through the runner, and its OWN rbox_tracker.py through
+the overlay."""
 import json
 import os
 import subprocess
@@ -352,3 +356,98 @@ def test_tracker_tool_on_the_device_uses_the_hip_iou(tmp_path, golden):
     assert rep["ran"] and rep["iou"] == "bev_amd.iou"
     iou, dets, trks = (np.load(str(out) + s) for s in (".iou.npy", ".dets.npy", ".trks.npy"))
     np.testing.assert_allclose(iou, co.rbox_iou(dets, trks), rtol=0, atol=1e-12)
+
+
+REFERENCE = "/root/reference"  # present in the build container only (never on the GPU box; nothing of it is copied)
+
+REAL_CV2_STUB = '''
+"""inert stand-in for OpenCV (harness side): the decode names vis_homo.py touches before / around its warp"""
+import numpy as np
+CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT = 3, 4
+INTER_LINEAR = 1
+
+
+class VideoCapture:
+    def __init__(self, path):
+        self.n = 0
+
+    def get(self, prop):
+        return {3: 1920.0, 4: 1080.0}[prop]
+
+    def isOpened(self):
+        return True
+
+    def read(self):
+        if self.n >= 1:
+            return False, None
+        self.n += 1
+        return True, np.random.default_rng(1234).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+
+    def release(self):
+        pass
+
+
+def warpPerspective(*a, **k):
+    raise AssertionError("the stub's own warpPerspective ran: the rebinding did not happen")
+'''
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "vis_homo.py")), reason="the reference is only present in the build container")
+def test_the_reference_vis_homo_itself_runs_unchanged_through_the_runner(tmp_path, golden):
+    """/root/reference/vis_homo.py, byte for byte, through `python -m bev_amd.run` with an inert cv2 stand-in for the decoder:
+    `import bev` is the overlay, `bev.io.utils` / `bev.visualizer.homo_vis` are the reference's own files, load_calib /
+    load_bspec / Calib.scale are bev_amd's -- and print the values the reference itself prints for this calibration (SURVEY.md
+    8(c): center_world [4.67193551 1.32144698 1.], small [4.64784341 1.31490458 1.]) -- and cv2.warpPerspective (vis_homo.py:89)
+    lands in bev_amd.  Without a device the call stops there, inside bev_amd/warp.py; with one it would return the BEV frame."""
+    site = tmp_path / "site"
+    site.mkdir()
+    (site / "cv2.py").write_text(REAL_CV2_STUB)
+    calib = tmp_path / "system_dubska_optimal_calib.json"
+    calib.write_text(json.dumps(golden["brno_file"]["json"]))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, str(site)])
+    r = subprocess.run([sys.executable, "-m", "bev_amd.run", os.path.join(REFERENCE, "vis_homo.py"), "--video-tag", "6_left", "--video-path", "none.avi",
+                        "--calib-path", str(calib), "--no-show", "--no-grid"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "center_world [4.67193551 1.32144698 1." in out and "center_world_small [4.64784341 1.31490458 1." in out, out[-2000:]
+    assert "the stub's own warpPerspective ran" not in out
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, out[-2000:]
+    else:  # the frame's upload is where a machine without a device stops: inside bev_amd, reached through cv2.warpPerspective
+        assert r.returncode != 0 and os.path.join("bev_amd", "warp.py") in out and "in warpPerspective" in out, out[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "bev", "tracker", "rbox_tracker.py")), reason="the reference is only present in the build container")
+def test_the_reference_sort_loads_through_the_overlay_with_the_hip_iou_bound(tmp_path):
+    """`from bev.tracker.rbox_tracker import Sort` (rbox_tracking_BrnoCompSpeed.py:1) against the reference's own file: its
+    third-party imports are stubbed (filterpy, skimage; d3d gets bev_amd's stand-in), `Sort` and
+    `associate_detections_to_trackers` are the reference's objects and look up bev_amd's iou_batch_rbox."""
+    site = tmp_path / "site"
+    (site / "filterpy").mkdir(parents=True)
+    (site / "skimage").mkdir()
+    (site / "cv2.py").write_text(REAL_CV2_STUB)
+    (site / "filterpy" / "__init__.py").write_text("")
+    (site / "filterpy" / "kalman.py").write_text("class KalmanFilter:\n    def __init__(self, *a, **k):\n        pass\n\n\nclass ExtendedKalmanFilter(KalmanFilter):\n    pass\n")
+    (site / "skimage" / "__init__.py").write_text("from . import io\n")
+    (site / "skimage" / "io.py").write_text("")
+    code = textwrap.dedent('''
+        import json, sys
+        import matplotlib
+        _use = matplotlib.use
+        matplotlib.use = lambda *a, **k: _use("Agg")   # the reference asks for TkAgg at import: no display here
+        import bev_amd.patch as patch
+        patch.install()
+        from bev.tracker.rbox_tracker import Sort, associate_detections_to_trackers
+        import bev.tracker.rbox_tracker as rt
+        print(json.dumps({"Sort": Sort.__module__, "file": rt.__shadowed_file__, "err": str(rt.__shadowed_error__),
+                          "iou": associate_detections_to_trackers.__globals__["iou_batch_rbox"].__module__,
+                          "d3d": bool(getattr(sys.modules.get("d3d"), "__bev_amd_stand_in__", False))}))
+    ''')
+    env = dict(os.environ, MPLBACKEND="Agg")
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, str(site), REFERENCE])
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["Sort"] == "bev.tracker.rbox_tracker" and rep["file"] == os.path.join(REFERENCE, "bev", "tracker", "rbox_tracker.py") and rep["err"] == "None"
+    assert rep["iou"] == "bev_amd.iou"
