@@ -2,7 +2,8 @@
 
 composite_reg_img   alpha blend  fg * m + bg * (1 - m), m = mask / 255, rounded and clipped to uint8 (compo.py:5-24):
                     one HIP launch in float64 like the reference's numpy expression (bevwarp_composite)
-composite_bev_img   background, foreground and mask warped into the BEV and blended (compo.py:26-49) in ONE launch
+composite_bev_img   background, foreground and mask warped into the BEV and blended (compo.py:26-49) in ONE launch, bw_mode's
+                    grey conversion of the foreground included (tap by tap, inside the kernel)
                     (bevwarp_warp_composite): every BEV pixel samples the background through H_img2bev_fix and the
                     foreground + its mask through H_img2bev_cam and blends in registers; no warped image is ever written.
                     Bit-identical to three bevwarp_warp calls followed by bevwarp_composite.
@@ -95,8 +96,8 @@ def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_si
     bg, fg, fg_mask = (_hwc(_as_cuda(x, device)) for x in (bg, fg, fg_mask))
     if fg.shape != fg_mask.shape or bg.shape[2] != fg.shape[2]:
         raise ValueError("fg and fg_mask must have one shape, and bg their channel count")
-    if bw_mode:
-        fg = gray_bgr(fg)
+    if bw_mode and fg.shape[2] != 3:
+        raise ValueError("bw_mode needs a 3-channel BGR foreground (cv2.COLOR_BGR2GRAY), got shape %s" % (tuple(fg.shape),))
     minv, H_world2img_cam = _composite_maps(H_world2bev, H_img2world_fix, K, RT, bg.device)
     C = bg.shape[2]
     out = torch.empty((int(y_size), int(x_size), C), dtype=torch.uint8, device=bg.device)
@@ -105,6 +106,6 @@ def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_si
         st = _lib.load().bevwarp_warp_composite(
             bg.data_ptr(), bg.shape[0], bg.shape[1], bg.stride(0), fg.data_ptr(), fg_mask.data_ptr(), fg.shape[0], fg.shape[1], fg.stride(0),
             fg_mask.stride(0), out.data_ptr(), out.shape[0], out.shape[1], out.stride(0), C, minv.data_ptr(), minv.data_ptr() + 72,
-            ctypes.c_void_p(stream))
+            int(bool(bw_mode)), ctypes.c_void_p(stream))
     _lib.check(st)
     return _result(out, as_numpy), H_world2img_cam

@@ -238,11 +238,12 @@ int bevwarp_composite(const void* bg, const void* fg, const void* mask, void* ou
 
 int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_stride, const void* fg, const void* mask, int fg_h, int fg_w,
                            int64_t fg_row_stride, int64_t mask_row_stride, void* dst, int dst_h, int dst_w, int64_t dst_row_stride, int channels,
-                           const double* M_inv_bg, const double* M_inv_cam, void* stream) {
+                           const double* M_inv_bg, const double* M_inv_cam, int fg_gray, void* stream) {
     using namespace bevwarp;
     if (!bg || !fg || !mask || !dst || !M_inv_bg || !M_inv_cam) return BEVWARP_ERR_BAD_ARG;
     if (bg_h <= 0 || bg_w <= 0 || fg_h <= 0 || fg_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
     if (channels < 1 || channels > 4) return BEVWARP_ERR_UNSUPPORTED;
+    if (fg_gray && channels != 3) return BEVWARP_ERR_UNSUPPORTED;  // BGR2GRAY needs three channels
     if (bg_row_stride < (int64_t)bg_w * channels || fg_row_stride < (int64_t)fg_w * channels || mask_row_stride < (int64_t)fg_w * channels ||
         dst_row_stride < (int64_t)dst_w * channels)
         return BEVWARP_ERR_BAD_ARG;
@@ -271,6 +272,7 @@ int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_st
     a.xminv[0] = a.xminv[1] = M_inv_cam;
     a.xsrc_rs[0] = fg_row_stride, a.xsrc_rs[1] = mask_row_stride;
     a.xsrc_h[0] = a.xsrc_h[1] = fg_h, a.xsrc_w[0] = a.xsrc_w[1] = fg_w;
+    a.fg_gray = fg_gray != 0;
     // one 12-wave workgroup per tile, one workgroup per CU: the tallest tile (<= the LDS copies' 16 rows) that still gives every
     // CU a workgroup
     const int tw = tile_width(BEVWARP_U8);

@@ -36,6 +36,7 @@ struct WarpArgs {
     const double* xminv[2];
     int64_t xsrc_rs[2];
     int xsrc_h[2], xsrc_w[2];
+    int fg_gray;                 // composite, bw_mode: source 1 (the foreground) is converted to grey tap by tap
 };
 
 int tile_width(int dtype);   // destination pixels per row segment of one wave: 256 (8-bit) / 128 (float)

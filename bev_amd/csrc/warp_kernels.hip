@@ -219,6 +219,17 @@ __device__ __forceinline__ uint32_t blend_u8_rgb_window(uint32_t a0, uint32_t a1
     return __builtin_amdgcn_perm(s2, __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), 0x0c060100u);
 }
 
+// bw_mode of the composite (bev/tool/compo.py:13-14): the foreground is cv2.cvtColor(BGR2GRAY -> GRAY2BGR)'d BEFORE it is warped, so
+// the TAPS are converted -- OpenCV's 14-bit fixed point (1868 B + 9617 G + 4899 R + 8192) >> 14 on a pixel packed B, G, R in bytes
+// 0, 1, 2 (restated from OpenCV's colour conversion; parity unpinned) -- then one channel is blended and replicated.
+__device__ __forceinline__ uint32_t gray_of(uint32_t p) {
+    return ((p & 0xffu) * 1868u + ((p >> 8) & 0xffu) * 9617u + ((p >> 16) & 0xffu) * 4899u + 8192u) >> 14;
+}
+__device__ __forceinline__ uint32_t blend_u8_gray_window(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t fx, uint32_t fy) {
+    const uint32_t g = blend_u8(gray_of(a0), gray_of(__builtin_amdgcn_alignbit(a1, a0, 24)), gray_of(b0), gray_of(__builtin_amdgcn_alignbit(b1, b0, 24)), fx, fy);
+    return g * 0x010101u;
+}
+
 // What the guarded sampler needs of the source frame, by value (taking the address of the kernel-argument struct would
 // push it to scratch).
 struct SrcView {
@@ -227,6 +238,7 @@ struct SrcView {
     int w, h;
     float bf[4];
     uint32_t bu;  // border bytes packed
+    bool gray;    // (composite, bw_mode) 8-bit BGR taps are converted to grey before they are blended
 };
 
 template <typename T>
@@ -286,6 +298,15 @@ __device__ __forceinline__ Pixel<T, C> sample_global(const SrcView& a, int X, in
         t01[k] = r0[(int64_t)cx1 * C + k];
         t10[k] = r1[(int64_t)cx0 * C + k];
         t11[k] = r1[(int64_t)cx1 * C + k];
+    }
+    if constexpr (sizeof(T) == 1 && C == 3) {
+        if (a.gray) {
+            auto tap = [&](const T (&t)[C], bool in) {
+                return in ? ((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16)) : (a.bu & 0xffffffu);
+            };
+            out.packed = blend_u8(gray_of(tap(t00, xin0 && yin0)), gray_of(tap(t01, xin1 && yin0)), gray_of(tap(t10, xin0 && yin1)), gray_of(tap(t11, xin1 && yin1)), fx, fy) * 0x010101u;
+            return out;
+        }
     }
     float w00 = 0, w01 = 0, w10 = 0, w11 = 0;
     if constexpr (sizeof(T) == 4) weights_f32(fx, fy, w00, w01, w10, w11);
@@ -431,6 +452,8 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     view.rs = src_rs;
     view.w = src_w;
     view.h = src_h;
+    const bool gray_src = NSRC > 1 && sizeof(T) == 1 && C == 3 && sid == 1 && a.fg_gray != 0;  // (constant false in the plain kernel)
+    view.gray = gray_src;
 #pragma unroll
     for (int k = 0; k < 4; k++) view.bf[k] = a.bval_f[k];
     view.bu = (uint32_t)a.bval_u8[0] | ((uint32_t)a.bval_u8[1] << 8) | ((uint32_t)a.bval_u8[2] << 16) | ((uint32_t)a.bval_u8[3] << 24);
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             if constexpr (INTERP == kNearest)
                 px = C == 4 ? w0[0] : (w0[0] & ((1u << (8 * (C & 3))) - 1u));
             else if constexpr (C == 3)
-                px = blend_u8_rgb_window(w0[0], w0[1], w1[0], w1[1], fx, fy);
+                px = gray_src ? blend_u8_gray_window(w0[0], w0[1], w1[0], w1[1], fx, fy) : blend_u8_rgb_window(w0[0], w0[1], w1[0], w1[1], fx, fy);
             else if constexpr (C == 4)
                 px = blend_u8_packed<C>(w0[0], w0[1], w1[0], w1[1], fx, fy);
             else
@@ -768,7 +791,8 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
                     if (INTERP == kNearest)
                         v.packed = C == 4 ? e0[j].w[0] : (e0[j].w[0] & ((1u << (8 * (C & 3))) - 1u));
                     else if constexpr (C == 3)
-                        v.packed = blend_u8_rgb_window(e0[j].w[0], e0[j].w[1], e1[j].w[0], e1[j].w[1], fx, fy);
+                        v.packed = gray_src ? blend_u8_gray_window(e0[j].w[0], e0[j].w[1], e1[j].w[0], e1[j].w[1], fx, fy)
+                                            : blend_u8_rgb_window(e0[j].w[0], e0[j].w[1], e1[j].w[0], e1[j].w[1], fx, fy);
                     else if constexpr (C == 4)
                         v.packed = blend_u8_packed<C>(e0[j].w[0], e0[j].w[1], e1[j].w[0], e1[j].w[1], fx, fy);
                     else

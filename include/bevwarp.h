@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BEVWARP_ABI_VERSION 3
+#define BEVWARP_ABI_VERSION 4
 
 typedef enum bevwarp_status {
     BEVWARP_OK = 0,
@@ -126,11 +126,14 @@ int bevwarp_composite(const void *bg, const void *fg, const void *mask, void *ou
  * three-warp sequence.
  *   bg (bg_h x bg_w), fg and mask (fg_h x fg_w each), dst: device uint8, `channels` (1..4) interleaved, strides in bytes.
  *   M_inv_bg, M_inv_cam: device, 9 float64 each, INVERSE maps (dst px -> bg px / camera px).
+ *   fg_gray: non-zero = the reference's bw_mode (compo.py:13-14): the foreground is converted BGR -> grey -> BGR before it is
+ *            warped, i.e. tap by tap ((1868 B + 9617 G + 4899 R + 8192) >> 14, OpenCV's 8-bit form); channels must be 3.
+ * Overlap of dst with a source: BEVWARP_ERR_BAD_ARG.
  */
 int bevwarp_warp_composite(const void *bg, int bg_h, int bg_w, int64_t bg_row_stride, const void *fg, const void *mask,
                            int fg_h, int fg_w, int64_t fg_row_stride, int64_t mask_row_stride, void *dst, int dst_h,
                            int dst_w, int64_t dst_row_stride, int channels, const double *M_inv_bg,
-                           const double *M_inv_cam, void *stream);
+                           const double *M_inv_cam, int fg_gray, void *stream);
 
 /*
  * Marks every in-bounds source pixel that any tap of any destination pixel of the same warp would

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert getattr(raw, n) is not None
-    assert lib.bevwarp_version() == _lib.ABI_VERSION == 3
+    assert lib.bevwarp_version() == _lib.ABI_VERSION == 4
 
 
 def test_header_cites_the_reference_interfaces():

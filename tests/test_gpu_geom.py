@@ -331,6 +331,14 @@ def test_warp_composite_every_channel_count(c):
         exp = np.minimum((ff * (fm / 255) + fb * (1 - fm / 255)).round(), 255).astype(np.uint8)
         np.testing.assert_array_equal(got.cpu().numpy(), exp)
         assert 0.02 < (fm > 0).mean() < 1.0  # the camera footprint really is cut by the frame's edge and not empty
+        if c == 3:  # bw_mode (compo.py:13-14): the foreground goes BGR -> grey -> BGR BEFORE the warp; the kernel converts its taps
+            gotg, _ = composite_bev_img(torch.from_numpy(bg).cuda(), fg, mask, H_world2bev, H_img2world_fix, Ks, RT, dw, dh, bw_mode=True)
+            g = ((fg[..., 0].astype(np.int64) * 1868 + fg[..., 1].astype(np.int64) * 9617 + fg[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+            fgg = np.ascontiguousarray(np.repeat(g[..., None], 3, 2))
+            ffg = co.warp_perspective(fgg, Hc, (dw, dh)).astype(np.float64)
+            expg = np.minimum((ffg * (fm / 255) + fb * (1 - fm / 255)).round(), 255).astype(np.uint8)
+            np.testing.assert_array_equal(gotg.cpu().numpy(), expg)
+            assert not np.array_equal(expg, exp)
     if c != 3:
         with pytest.raises(ValueError):
             composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, Ks, RT, dw, dh, bw_mode=True)
