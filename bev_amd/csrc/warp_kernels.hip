@@ -207,16 +207,24 @@ __device__ __forceinline__ uint32_t blend_u8_packed(uint32_t p00, uint32_t p01, 
 }
 
 // 8-bit RGB straight from a tap window: (a1:a0) / (b1:b0) hold bytes 0..7 of the upper / lower source row starting
-// at the left tap (left pixel = bytes 0 1 2, right pixel = bytes 3 4 5); the byte selects do the unpacking.
+// at the left tap (left pixel = bytes 0 1 2, right pixel = bytes 3 4 5).  VERTICAL FIRST: the byte selects unpack channel c
+// of both rows into (L.c, R.c) u16 pairs, v_pk_mul_lo_u16 + v_pk_mad_u16 blend the two rows of both taps at once
+// (wy0 t + wy1 b <= 8160), and one v_dot2_u32_u16 per channel does the horizontal sum with the rounding constant, the
+// weights scaled by 64 so that the result byte is bits 16..23: 6 perm + 3 mul + 3 mad + 3 dot2 + 2 perm = 17, against 19
+// for horizontal-first (4 perm + 6 dot4 + 3 lshl_or + 3 dot2 + 2 perm + one more weight).
 __device__ __forceinline__ uint32_t blend_u8_rgb_window(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t fx, uint32_t fy) {
-    const uint32_t wlo = fx * 255u + 32u, whi = wlo << 16;
-    const uint32_t wy01 = fy * 0x3fffc0u + 2048u;  // halves (2048 - 64 fy, 64 fy)
-    const uint32_t t01 = __builtin_amdgcn_perm(a1, a0, 0x04010300u), u01 = __builtin_amdgcn_perm(b1, b0, 0x04010300u);  // L.c0 R.c0 L.c1 R.c1
-    const uint32_t t2 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0502u), u2 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0502u);    // L.c2 R.c2 0 0
-    const uint32_t s0 = vblend_u8(__builtin_amdgcn_udot4(t01, wlo, 0u, false), __builtin_amdgcn_udot4(u01, wlo, 0u, false), wy01);
-    const uint32_t s1 = vblend_u8(__builtin_amdgcn_udot4(t01, whi, 0u, false), __builtin_amdgcn_udot4(u01, whi, 0u, false), wy01);
-    const uint32_t s2 = vblend_u8(__builtin_amdgcn_udot4(t2, wlo, 0u, false), __builtin_amdgcn_udot4(u2, wlo, 0u, false), wy01);
-    return __builtin_amdgcn_perm(s2, __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), 0x0c060100u);
+    const u16x2 wx = __builtin_bit_cast(u16x2, fx * 0x3fffc0u + 2048u);  // halves (2048 - 64 fx, 64 fx)
+    const unsigned short wy1 = (unsigned short)fy, wy0 = (unsigned short)(32u - fy);
+    const u16x2 wy0p = {wy0, wy0}, wy1p = {wy1, wy1};
+    uint32_t s[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const uint32_t sel = 0x0c030c00u + 0x00010001u * c;  // (byte c, 0, byte c + 3, 0)
+        const u16x2 t = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(a1, a0, sel));
+        const u16x2 b = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(b1, b0, sel));
+        s[c] = __builtin_amdgcn_udot2(t * wy0p + b * wy1p, wx, 32768u, false);
+    }
+    return __builtin_amdgcn_perm(s[2], __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u), 0x0c060100u);
 }
 
 // bw_mode of the composite (bev/tool/compo.py:13-14): the foreground is cv2.cvtColor(BGR2GRAY -> GRAY2BGR)'d BEFORE it is warped, so
@@ -351,6 +359,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (s_memtime) and the 100 MHz reference ticks (s_memrealtime) it lived for; their ratio is the clock the chip held.
 #ifdef BEVWARP_CLOCK
 __device__ unsigned long long g_clk[4];
+#endif
+#ifndef BEVWARP_DEEP_ALL
+#define BEVWARP_DEEP_ALL 0  // (experiment: several passes in flight for every format)
+#endif
+#ifndef BEVWARP_DEPTH
+#define BEVWARP_DEPTH 6
 #endif
 // waves per SIMD a format's kernel is compiled for: what its interior loop needs without spilling
 constexpr int waves_per_simd_of(bool is_u8, int channels, int interp) {
@@ -1144,6 +1158,50 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
             finish_s(C0, C1, C2, u0, u1);
             note_ties(C1, C2);
         };
+        // Nearest neighbour: the taps of up to kDepth passes in flight -- a ring of pass slots; the loads of a pass are issued as soon
+        // as the slot's previous pass has been put away, and with kDepth = 6 every pass of a wave over a 24-row tile has its loads out
+        // before the first is consumed (a tap is one dword per pixel: 4 registers per slot).  A nearest pass has next to no arithmetic
+        // to hide its loads behind, so the depth is what it runs at -- A/B on one box, 48 rounds, buffer sets drawn at random
+        // (profiles/r03_late_ab.txt): depth 1 / 2 / 4 / 6 = 58.2 / 56.8 / 54.9 / 51.1 us per 32 frames (-12 %), a 25-degree
+        // footprint 66.9 -> 63.2.  Bilinear taps do not respond to depth at all (8-bit 80.1 -> 80.8 us, float 199.0 -> 199.3 at depth 2;
+        // depth 3 does not fit 128 registers): those kernels do not wait on latency.
+        constexpr bool kDeep = kDefer && (INTERP == kNearest || BEVWARP_DEEP_ALL);
+        if constexpr (kDeep) {
+            constexpr int kDepth = BEVWARP_DEPTH;  // passes in flight
+            uint32_t R0[kDepth][PPL], R1[kDepth][PPL], R2[kDepth][PPL];  // ring of pass states (nearest: dead once the loads are out)
+            Bytes<WINB> r0[kDepth][PPL], r1[kDepth][PPL];
+            bool live[kDepth];
+            bool any = true;  // passes are issued in order: the first slot that finds none ends the tile
+#pragma unroll
+            for (int d = 0; d < kDepth; d++) {
+                live[d] = any && (d == 0 || next_pass(own, p_nxt));
+                any = live[d];
+                if (live[d]) {
+                    coords_f(p_nxt, R0[d], R1[d], R2[d]);
+                    note_ties(R1[d], R2[d]);
+                    issue_s(kFast, R0[d], r0[d], r1[d]);
+                }
+            }
+            int kb = 0;
+            for (bool done = false; !done;) {
+#pragma unroll
+                for (int d = 0; d < kDepth; d++) {
+                    if (done || !live[d]) {
+                        done = true;
+                        continue;
+                    }
+                    lds_row(kb++);
+                    finish_s(R0[d], R1[d], R2[d], r0[d], r1[d]);
+                    any = any && next_pass(own, p_nxt);
+                    live[d] = any;
+                    if (any) {
+                        coords_f(p_nxt, R0[d], R1[d], R2[d]);
+                        note_ties(R1[d], R2[d]);
+                        issue_s(kFast, R0[d], r0[d], r1[d]);
+                    }
+                }
+            }
+        } else {
         coords_f(p_nxt, A0, A1, A2);
         issue_s(kFast, A0, u0, u1);
         p_cur = p_nxt;
@@ -1160,6 +1218,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         if constexpr (!kDefer) {
             read_back(out);
             store_s(own, pass_x(p_cur), p_cur.y, out);
+        }
         }
         if (__builtin_expect(tie_passes != 0, 0)) {  // redo the flagged passes: every pixel by the exact chain and the generic sampler
             Pass p;

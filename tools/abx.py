@@ -91,12 +91,17 @@ def main():
             launch(fn, it % nsets)
             it += 1
     torch.cuda.synchronize()
+    rng = np.random.default_rng(7)
+    last = -1
     for r in range(args.rounds):
-        order = libs if r % 2 == 0 else libs[::-1]
+        order = [libs[i] for i in rng.permutation(len(libs))]  # (a fixed order ties every library to its own buffer sets)
         for label, fn in order:
+            k = int(rng.integers(nsets - 1))
+            k = k if k < last else k + 1 if last >= 0 else k  # any set but the one just used (still warm in the caches)
+            last = k
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(fn, it % nsets)
+            launch(fn, k)
             e1.record()
             it += 1
             e1.synchronize()
