@@ -366,6 +366,12 @@ __device__ unsigned long long g_clk[4];
 #ifndef BEVWARP_DEPTH
 #define BEVWARP_DEPTH 6
 #endif
+#ifndef BEVWARP_STRAIGHT
+#define BEVWARP_STRAIGHT 1
+#endif
+#ifndef BEVWARP_AHEAD
+#define BEVWARP_AHEAD 2  // bilinear: passes of taps in flight in the straight-line form
+#endif
 // waves per SIMD a format's kernel is compiled for: what its interior loop needs without spilling
 constexpr int waves_per_simd_of(bool is_u8, int channels, int interp) {
     return interp == kLinear && (is_u8 || channels == 4) ? BEVWARP_U8LIN_WAVES : 4;
@@ -1163,10 +1169,49 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         // before the first is consumed (a tap is one dword per pixel: 4 registers per slot).  A nearest pass has next to no arithmetic
         // to hide its loads behind, so the depth is what it runs at -- A/B on one box, 48 rounds, buffer sets drawn at random
         // (profiles/r03_late_ab.txt): depth 1 / 2 / 4 / 6 = 58.2 / 56.8 / 54.9 / 51.1 us per 32 frames (-12 %), a 25-degree
-        // footprint 66.9 -> 63.2.  Bilinear taps do not respond to depth at all (8-bit 80.1 -> 80.8 us, float 199.0 -> 199.3 at depth 2;
-        // depth 3 does not fit 128 registers): those kernels do not wait on latency.
+        // footprint 66.9 -> 63.2.  (Behind the ring's branches the compiler cannot count the loads issued after the ones a pass
+        // consumes and waits for vmcnt(0): the ring only pays once everything is issued up front.  Full-height tiles take the
+        // straight-line form below, whose counts are exact; the ring is what ragged tiles run.)
         constexpr bool kDeep = kDefer && (INTERP == kNearest || BEVWARP_DEEP_ALL);
-        if constexpr (kDeep) {
+        // A wave with a full set of rows (kRowsLds passes: every wave of a full-height tile) runs them as STRAIGHT-LINE code.  Only
+        // there does the compiler know how many loads were issued after the ones a pass is about to consume -- behind a loop's or the
+        // ring's branches it has to assume none and waits for vmcnt(0), i.e. for every load in flight, the newest included.  Nearest:
+        // all six passes' loads up front.  Bilinear: TWO tap sets, the loads of pass n + 2 issued right after pass n has been
+        // blended and consumed after pass n + 1 has, under s_waitcnt vmcnt(13..8) -- a whole step in flight instead of the
+        // coordinate stage of one: 8-bit row-affine tiles 80.1 -> 77.1 us per 32 frames (-3.7 %; A/B, profiles/r03_late_ab.txt),
+        // float unchanged (191.5: it runs at the streaming rate either way).  The same two sets behind a loop's branches measured
+        // nothing at all (80.1 -> 80.8): the waits, not the loads, were what did not overlap.  A third set does not fit 128
+        // registers (the scheduler sinks its loads back to where two sets put them); the general chain spills with two.
+        bool straight = false;
+        if constexpr (kDefer && !kBlk && BEVWARP_STRAIGHT && (INTERP == kNearest || kAff || sizeof(T) == 4)) {  // (8-bit bilinear, general chain: two tap sets spill)
+            constexpr int kFull = kRowsLds;
+            constexpr int kAhead = INTERP == kNearest ? kFull : BEVWARP_AHEAD;  // passes of taps in flight
+            if ((y_last - p_nxt.y) / kWaves + 1 == kFull) {
+                straight = true;
+                uint32_t R0[kAhead][PPL], R1[kAhead][PPL], R2[kAhead][PPL];
+                Bytes<WINB> r0[kAhead][PPL], r1[kAhead][PPL];
+#pragma unroll
+                for (int k = 0; k < kAhead; k++) {
+                    coords_f(p_nxt, R0[k], R1[k], R2[k]);
+                    note_ties(R1[k], R2[k]);
+                    issue_s(kFast, R0[k], r0[k], r1[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < kFull; k++) {
+                    constexpr int kA = kAhead;
+                    const int d = k % kA;
+                    lds_row(k);
+                    finish_s(R0[d], R1[d], R2[d], r0[d], r1[d]);
+                    if (k + kA < kFull) {
+                        coords_f(p_nxt, R0[d], R1[d], R2[d]);
+                        note_ties(R1[d], R2[d]);
+                        issue_s(kFast, R0[d], r0[d], r1[d]);
+                    }
+                }
+            }
+        }
+        if (straight) {
+        } else if constexpr (kDeep) {
             constexpr int kDepth = BEVWARP_DEPTH;  // passes in flight
             uint32_t R0[kDepth][PPL], R1[kDepth][PPL], R2[kDepth][PPL];  // ring of pass states (nearest: dead once the loads are out)
             Bytes<WINB> r0[kDepth][PPL], r1[kDepth][PPL];
