@@ -216,6 +216,29 @@ def test_config2_batch32_1080p_to_1024(W, dtype):
         assert (lhs - rhs).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("dtype,interp,kind", [(np.uint8, 0, "keystone"), (np.uint8, 0, "brno"), (np.uint8, 1, "brno"), (np.uint8, 1, "rot25"),
+                                               (np.uint8, 0, "rot25"), (np.float32, 0, "keystone"), (np.float32, 1, "brno")])
+def test_config2_size_other_paths(W, dtype, interp, kind):
+    """configs[1]'s launch size (32 x 1080p -> 1024^2: 24-row tiles, full-height tiles as straight-line code, the tail split) on
+    the paths test_config2_batch32_1080p_to_1024 does not take: nearest neighbour (every pass issued up front), the Brno-style and a
+    25-degree footprint (patches, edge-cut and outside tiles).  Oracle on three frames of the batch."""
+    B, sw, sh, dw, dh = 32, 1920, 1080, 1024, 1024
+    base = {"keystone": wl.keystone_H, "brno": wl.synth_brno_H}[kind](sw, sh, dw, dh) if kind != "rot25" else wl.rotated_H(sw, sh, dw, dh, 25.0, 0.6)
+    Ms = np.stack([wl.jitter_H(base, i) for i in range(B)])
+    host = {i: wl.frame(60 + i, sh, sw, dtype) for i in (0, 17, 31)}
+    frames = torch.empty((B, sh, sw, 3), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device="cuda")
+    f0 = torch.from_numpy(host[0]).cuda()
+    for i in range(B):
+        frames[i] = torch.from_numpy(host[i]).cuda() if i in host else f0.flip(i % 2)
+    out = W.warp_perspective(frames, Ms, (dw, dh), flags=interp)
+    for i, f in host.items():
+        check(out[i].cpu().numpy(), co.warp_perspective(f, Ms[i], (dw, dh), interp, nthreads=8))
+    # a frame's result does not depend on its place in the batch (frames 1.. are flips of frame 0: redo one of them alone)
+    j = 6
+    alone = W.warp_perspective(frames[j:j + 1], Ms[j:j + 1], (dw, dh), flags=interp)
+    assert torch.equal(alone[0], out[j])
+
+
 def test_config4_single_4k_frame(W):
     """One frame of configs[3] (3840x2160 -> 2048x2048, uint8); the 8-GPU sharding is covered in test_shard.py."""
     sw, sh, dw, dh = 3840, 2160, 2048, 2048
