@@ -145,6 +145,18 @@ __device__ __forceinline__ double rcp_newton(double w) {
     return r;
 }
 
+// the wide destination store of a pass (experiment switch: non-temporal)
+#ifndef BEVWARP_NT_STORES
+#define BEVWARP_NT_STORES 0
+#endif
+template <typename V>
+__device__ __forceinline__ void wide_store(V* p, const V& v) {
+    if (BEVWARP_NT_STORES)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Blending.  u8: 15-bit fixed point of the reference == exact integer form
 //   (sum_i p_i * w_i * 32 + 2^14) >> 15  ==  (wy0 * (wx0 p00 + wx1 p01) + wy1 * (wx0 p10 + wx1 p11) + 512) >> 10
@@ -898,7 +910,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
                                (float)((p[2] >> (8 * k)) & 0xffu) * sc + bi, (float)((p[3] >> (8 * k)) & 0xffu) * sc + bi};
                     float* dk = reinterpret_cast<float*>(dp + k * a.dst_ps);
                     if (__builtin_expect(lane_vec, 1)) {
-                        *reinterpret_cast<f32x4*>(dk) = o;
+                        wide_store(reinterpret_cast<f32x4*>(dk), o);
                     } else {
                         for (int i = 0; i < lane_px; i++) dk[i] = o[i];
                     }
@@ -919,10 +931,10 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
                     *reinterpret_cast<u32x2*>(d) = o;
                 } else if constexpr (C == 3) {
                     u32x3 o = {p[0] | (p[1] << 24), (p[1] >> 8) | (p[2] << 16), (p[2] >> 16) | (p[3] << 8)};
-                    *reinterpret_cast<u32x3*>(d) = o;
+                    wide_store(reinterpret_cast<u32x3*>(d), o);
                 } else {
                     u32x4 o = {p[0], p[1], p[2], p[3]};
-                    *reinterpret_cast<u32x4*>(d) = o;
+                    wide_store(reinterpret_cast<u32x4*>(d), o);
                 }
             } else {
                 for (int i = 0; i < lane_px; i++)
@@ -957,7 +969,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
                 float* drow = reinterpret_cast<float*>(dframe + (int64_t)(y + r) * a.dst_rs) + (int64_t)xs * C;
                 if (__builtin_expect(a.dst_vec_ok && 4 * qr + 4 <= nfl, 1)) {
                     u32x4 o = {out[u].x, out[u].y, out[u].z, out[u].w};
-                    *(&reinterpret_cast<u32x4*>(drow)[qr]) = o;
+                    wide_store(&reinterpret_cast<u32x4*>(drow)[qr], o);
                 } else {
                     const uint32_t f[4] = {out[u].x, out[u].y, out[u].z, out[u].w};
                     for (int i = 0; i < 4 && 4 * qr + i < nfl; i++) reinterpret_cast<uint32_t*>(drow)[4 * qr + i] = f[i];
