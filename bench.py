@@ -18,8 +18,10 @@ ONE JSON line (rank 0).  At N = 1 it also carries, measured in the same run:
              nearest, uint8 -> float32 planes -- and the rotated "brno" footprint for uint8 and float32
   configs    configs[0] (one 720p -> 512^2 uint8 frame: GPU resident / PCIe-inclusive, CPU oracle 1 thread and all cores,
              cv2 when this box happens to have it), configs[2] (1e7 points, f32 / f64), configs[3] (the per-GPU shard,
-             uint8 and float32), configs[4] (1080p -> 1024^2 uint8 warp + the 512 x 512 tracker launch, eager and replayed
-             from a hipGraph), and the PCIe-inclusive frame pipeline
+             uint8 and float32), configs[4] (1080p -> 1024^2 uint8 warp + the 512 x 512 tracker launch), and the
+             PCIe-inclusive frame pipeline
+  summary    LAST key, <= 1500 characters: {entry: [ms per step (kernel mean), fraction of 8 TB/s, HBM traffic / algorithmic bytes,
+             GPU output == oracle]} for every variant and config above, so that the tail of the line alone carries every number
 `roofline.measured_ceiling_gbs` = what a pure streaming kernel with the headline's byte mix (its algorithmic source bytes
 read with plain 16-byte loads, its destination bytes written with plain 16-byte stores -- the warp's access kinds)
 reaches in THIS process on THIS box, on the headline's own buffers, just before the headline runs (tools/streamprobe.hip;
@@ -71,7 +73,8 @@ def parse():
     p.add_argument("--no-probe", action="store_true", help="skip the same-process streaming-ceiling probe and the in-kernel clock reading")
     p.add_argument("--no-variants", action="store_true", help="skip the extra measurements of configs[1] (N = 1)")
     p.add_argument("--no-configs", action="store_true", help="skip the configs block (N = 1)")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline sample")
+    p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall budget of the cpu_baseline sample (the oracle needs < 1 s of 16 cores to time)")
+    p.add_argument("--leg-steps", type=int, default=300, help="timed launches of every side measurement (variants, configs[3]); --steps governs the headline only")
     a = p.parse_args()
     shape = {1: ([1920, 1080], [1024, 1024]), 3: ([3840, 2160], [2048, 2048])}[a.config]
     a.src = a.src or shape[0]
@@ -411,12 +414,31 @@ class Workload:
         return r
 
 
-def variant_line(w, steps, warmup, barrier, label=None, probe=False):
+def oracle_check(w, frames=(0, -1)):
+    """The GPU output of buffer set 0 against the CPU oracle on the same bytes, for a couple of frames of the batch (the variants'
+    frames are generated on the device, so the source is read back first).  Run AFTER the timed region; checker only."""
+    from oracle import cpu_oracle as co
+    ok = True
+    for f in frames:
+        f = f % w.B
+        src = w.srcs[0][f].cpu().numpy()
+        exp = co.warp_perspective(src, w.Ms[f], (w.dw, w.dh), w.interp, nthreads=host_cores())
+        got = w.dsts[0][f].cpu().numpy()
+        if w.planar:  # float32 planes: float(v) * (1 / 255) + 0, float32 multiply then add (bev_amd.warp.warp_to_planar's defaults)
+            exp = (exp.astype(np.float32) * np.float32(1.0 / 255.0) + np.float32(0.0)).transpose(2, 0, 1)
+        ok = ok and bool(np.array_equal(got, exp))
+    return ok
+
+
+def variant_line(w, steps, warmup, barrier, label=None, probe=False, check=True):
     ceiling = measured_ceiling(w) if probe else None
     el, lm = w.run(steps, warmup, barrier)
-    return {"dtype": label or w.dtype, "interp": w.interp_name, "homography": w.homography,
-            "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4),
+    line = {"dtype": label or w.dtype, "interp": w.interp_name, "homography": w.homography,
+            "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
             "roofline": w.roofline(lm, ceiling=ceiling)}
+    if check:
+        line["matches_oracle"] = oracle_check(w)
+    return line
 
 
 # ---- the other configs of BASELINE.json, bounded (N = 1) -------------------------------------------------------------------
@@ -485,9 +507,16 @@ def config2(dev):
             project_points(ins[k[0] % nbuf], H, out=outs[k[0] % nbuf])
             k[0] += 1
 
-        t = event_times(step, 60, 6)
+        t = event_times(step, 300, 10)
         nbytes = N * 2 * esz * 2
+        # checker: the first and last 100,000 points of buffer 0 against the oracle (float64: 1e-13 relative, the bar of tests/test_gpu_geom.py;
+        # float32: the same float64 arithmetic rounded once, bit for bit)
+        from oracle import cpu_oracle as co
+        sl = np.r_[0:100_000, N - 100_000:N]
+        exp, got = co.project_points(ins[0].cpu().numpy()[sl], H), outs[0].cpu().numpy()[sl]
+        ok = bool(np.array_equal(got, exp)) if esz == 4 else bool(np.allclose(got, exp, rtol=1e-13, atol=0))
         res[dt] = {"us_mean": round(float(t.mean()) * 1e6, 2), "us_min": round(float(t.min()) * 1e6, 2), "Gpts_per_s": round(N / float(t.mean()) / 1e9, 2),
+                   "matches_oracle": ok,
                    "roofline": {"bound": "hbm", "achieved": round(nbytes / float(t.mean()) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(nbytes / float(t.mean()) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                 "kernel": "project_points_kernel<%s,2>" % ("float" if esz == 4 else "double"), "algorithmic_bytes_per_launch": nbytes}}
@@ -504,7 +533,7 @@ def config3(args, dev, barrier):
     res = {"workload": "32 x (3840x2160x3 -> 2048x2048x3) bilinear, keystone: one GPU's shard of the 256-frame, 8-GPU config"}
     for dt in ("u8", "f32"):
         w = Workload(a3, dt, "linear", 0, dev, device_frames=True)
-        res[dt] = variant_line(w, 12, 3, barrier)
+        res[dt] = variant_line(w, args.leg_steps, 5, barrier, check=True)
         del w
         torch.cuda.empty_cache()
     return res
@@ -513,7 +542,6 @@ def config3(args, dev, barrier):
 def config4(dev):
     """configs[4]: one camera frame's step -- 1080p -> 1024^2 uint8 bilinear warp + the tracker launch on 512 x 512 boxes."""
     from bev_amd import warp
-    from bev_amd.graph import GraphedStep
     from bev_amd.iou import rbox_iou
     from bev_amd.tracker_geom import tracker_geometry_step
     from tests import workloads as wl
@@ -536,20 +564,16 @@ def config4(dev):
         tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf)
         k[0] += 1
 
-    te = event_times(step, 200, 20)
-    tt = event_times(lambda: tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf), 200, 20)
-    ti = event_times(lambda: rbox_iou(dets, trks), 200, 20)
-    res = {"workload": "one 1920x1080 uint8 frame -> 1024x1024 BEV (bilinear, synth-brno) + bevwarp_tracker_step on 512 detections x 512 tracks (float64)",
+    te = event_times(step, 300, 20)
+    tt = event_times(lambda: tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf), 300, 20)
+    ti = event_times(lambda: rbox_iou(dets, trks), 300, 20)
+    from oracle import cpu_oracle as co  # checker, after the timed launches
+    ok = bool(np.array_equal(outs[(k[0] - 1) % 4].cpu().numpy(), co.warp_perspective(wl.frame((k[0] - 1) % 4, 1080, 1920, np.uint8), M, (1024, 1024), 1, nthreads=host_cores())))
+    ok = ok and bool(np.allclose(buf["iou"].cpu().numpy(), co.rbox_iou(buf["dets_world"].cpu().numpy(), trks.cpu().numpy()[:, :5]), rtol=0, atol=1e-12))
+    res = {"matches_oracle": ok, "workload": "one 1920x1080 uint8 frame -> 1024x1024 BEV (bilinear, synth-brno) + bevwarp_tracker_step on 512 detections x 512 tracks (float64)",
            "step_eager_us": round(float(te.mean()) * 1e6, 1), "step_eager_us_min": round(float(te.min()) * 1e6, 1),
            "tracker_launch_us": round(float(tt.mean()) * 1e6, 1), "rbox_iou_512x512_us": round(float(ti.mean()) * 1e6, 1)}
-    try:
-        g = GraphedStep(step)
-        tg = event_times(g.replay, 200, 20)
-        res["step_graph_us"] = round(float(tg.mean()) * 1e6, 1)
-        res["step_graph_us_min"] = round(float(tg.min()) * 1e6, 1)
-    except Exception as e:  # graph capture is an optimisation of the harness, not of the path
-        res["step_graph_error"] = "%s: %s" % (type(e).__name__, e)
-    return res
+    return res  # (a hipGraph replay of these two launches measures SLOWER than issuing them: tools/bench_geom.py, tools/graphed_step.py)
 
 
 def composite_config(dev):
@@ -629,6 +653,59 @@ def _pipeline_rate(pipe, img):
     return (time.perf_counter() - t0) / n
 
 
+def summary_of(result):
+    """{entry: [ms per step (kernel mean), fraction of 8 TB/s, HBM traffic / algorithmic bytes, GPU output == oracle]}; null where an
+    entry has no such figure (latency-bound configs have no roofline fraction; traffic exists for the profiled workloads only)."""
+    def r4(v):
+        return None if v is None else float("%.4g" % v)
+
+    def of_line(line, ok=None):
+        rf = line["roofline"]
+        tr = rf.get("traffic")
+        return [r4(rf["kernel_ms_mean"]), r4(rf["frac"]), None if not tr else r4(tr / rf["algorithmic_bytes_per_launch"]), line.get("matches_oracle", ok)]
+
+    hom = {"keystone": "key", "brno": "brno"}
+    cb = result.get("cpu_baseline") or {}
+    head = dict(result, matches_oracle=cb.get("gpu_output_matches_oracle"))
+    out = {"%s_%s_%s" % (result["dtype"], "lin" if "linear" in result["config"]["workload"] else "near",
+                         "brno" if "brno" in result["config"]["workload"] else "key"): of_line(head)}
+    for v in result.get("variants", []):
+        name = "%s_%s_%s" % ("u8_planar" if "planar" in v["dtype"] else v["dtype"], "lin" if v["interp"] == "linear" else "near", hom[v["homography"]])
+        out[name] = of_line(v)
+    cfg = result.get("configs", {})
+
+    def us(d, key):
+        return None if d.get(key) is None else r4(d[key] * 1e-3)
+
+    c0 = cfg.get("configs[0]", {}).get("gpu_resident")
+    if c0:
+        out["c0_720p"] = [us(c0, "us_median"), None, None, c0.get("matches_oracle")]
+    for dt in ("f32", "f64"):
+        c2 = cfg.get("configs[2]", {}).get(dt)
+        if c2:
+            out["c2_pts_" + dt] = [us(c2, "us_mean"), r4(c2["roofline"]["frac"]), None, c2.get("matches_oracle")]
+    for dt in ("u8", "f32"):
+        c3 = cfg.get("configs[3]", {}).get(dt)
+        if c3:
+            out["c3_4k_" + dt] = of_line(c3)
+    c4 = cfg.get("configs[4]", {})
+    if "step_eager_us" in c4:
+        out["c4_step"] = [us(c4, "step_eager_us"), None, None, c4.get("matches_oracle")]
+        out["c4_tracker"] = [us(c4, "tracker_launch_us"), None, None, None]
+        out["c4_iou"] = [us(c4, "rbox_iou_512x512_us"), None, None, None]
+    f3 = cfg.get("f3_composite", {})
+    if "one_launch_us" in f3:
+        out["f3_comp"] = [us(f3, "one_launch_back_to_back_us"), None, None, f3.get("one_launch_equals_three_warps_plus_blend")]
+    pc = cfg.get("pcie_pipeline", {})
+    if "pipelined_ms_per_frame" in pc:
+        out["pcie_frame"] = [r4(pc["pipelined_ms_per_frame"]), None, None, None]
+    if cb:
+        out["cpu_mpix_s"] = [r4(cb["value"]), cb.get("cores")]
+    for k in [k for k, v in cfg.items() if "error" in v]:
+        out[k] = "error"
+    return out
+
+
 def main():
     args = parse()
     from bev_amd import shard
@@ -639,13 +716,13 @@ def main():
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    # Rehearsal knobs for a 1-GPU box (never needed on a real node): BEV_BENCH_SAME_DEVICE=1 puts every rank on
-    # device 0 and BEV_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    # Rehearsal knob for a 1-GPU box (never needed on a real node): BEV_BENCH_SAME_DEVICE=1 puts every rank on device 0
+    # (tests/test_gpu_shard.py runs the whole N = 2 bench that way).  BEV_BENCH_BACKEND overrides the control-plane backend.
     dev_index = 0 if os.environ.get("BEV_BENCH_SAME_DEVICE") == "1" else local_rank
-    backend = os.environ.get("BEV_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("BEV_BENCH_BACKEND", shard.CONTROL_BACKEND)  # gloo: the group carries a barrier and three scalar reductions, on CPU tensors
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    shard.init(backend=backend, device=dev)  # no-op for one process; RCCL only carries the barrier / max below
+    shard.init(backend=backend, device=dev)  # no-op for one process; no RCCL communicator is created (north_star: no collectives)
 
     big = args.config == 3
     main_wl = Workload(args, args.dtype, args.interp, rank, dev, device_frames=big and args.no_cpu_baseline)
@@ -690,7 +767,7 @@ def main():
 
     if world == 1 and not args.no_variants:
         variants = []
-        n = max(20, args.steps // 2)
+        n = max(args.leg_steps, args.steps)
         for dt, ip, planar, hom in (("u8", "linear", False, "keystone"), ("u8", "nearest", False, "keystone"), ("f32", "linear", False, "keystone"),
                                     ("u8", "linear", True, "keystone"), ("u8", "linear", False, "brno"), ("f32", "linear", False, "brno"),
                                     ("u8", "nearest", False, "brno")):
@@ -715,6 +792,8 @@ def main():
         result["configs"] = cfg
 
     if rank == 0:
+        if world == 1:
+            result["summary"] = summary_of(result)  # LAST key: the tail of the line alone carries every number
         print(json.dumps(result), flush=True)
     shard.barrier()
     if world > 1:

@@ -1,7 +1,7 @@
 """One rank of the N > 1 path, as a fresh process (started by tests/test_gpu_shard.py with RANK / WORLD_SIZE / MASTER_* set):
 joins the process group, warps ITS frame_shard of the global batch through the HIP library, saves the result.  Nothing is
 exchanged between ranks on the data path; the process group carries the barrier and the max-over-ranks time only -- exactly
-what bench.py --gpus N does.  `gloo` + one device stands in for RCCL + N devices on a one-GPU box."""
+what bench.py --gpus N does.  One device stands in for N on a one-GPU box; the control plane is gloo there and on a real node alike."""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ def main():
     sw, sh, dw, dh = (int(v) for v in sys.argv[3:7])
     from bev_amd import shard, warp
     from tests import workloads as wl
-    rank, _, world = shard.init(backend=os.environ.get("BEV_BENCH_BACKEND", "gloo"))
+    rank, _, world = shard.init(backend=os.environ.get("BEV_BENCH_BACKEND"))  # (None: the package's control backend, gloo)
     dev = torch.device("cuda", 0 if os.environ.get("BEV_BENCH_SAME_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     a, b = shard.frame_shard(n_frames, world, rank)

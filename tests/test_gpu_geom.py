@@ -197,7 +197,7 @@ def test_config5_full_step_eager_and_graphed():
     """BASELINE.json configs[4] as one per-camera step: 1080p -> 1024^2 uint8 BEV warp + the tracker launch on 512 x 512
     boxes, launched eagerly and replayed from a captured graph on new frames / boxes."""
     from bev_amd import warp as W
-    from bev_amd.graph import GraphedStep
+    from tools.graphed_step import GraphedStep
     from bev_amd.tracker_geom import tracker_geometry_step
     from tests import workloads as wl
     n = m = 512

@@ -171,9 +171,9 @@ def test_planar_normalised_output(W, interp, c, dw, dh):
 
 
 def test_graphed_step_replays_bit_exactly(W):
-    """bev_amd.graph.GraphedStep: warp + composite + tracker geometry captured once, replayed on new inputs."""
+    """tools.graphed_step.GraphedStep: warp + composite + tracker geometry captured once, replayed on new inputs."""
     from bev_amd.compo import composite_reg_img
-    from bev_amd.graph import GraphedStep
+    from tools.graphed_step import GraphedStep
     M = wl.synth_brno_H(640, 360, 512, 64)
     src = torch.zeros((360, 640, 3), dtype=torch.uint8, device="cuda")
     out = torch.empty((64, 512, 3), dtype=torch.uint8, device="cuda")

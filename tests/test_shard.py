@@ -49,3 +49,37 @@ def test_two_rank_gloo_run(tmp_path):
     assert rows[:, 0].tolist() == list(range(n_frames))  # every frame exactly once, in order
     exp = [int(np.random.default_rng(1234 + i).integers(0, 256, (4, 6, 3), dtype=np.uint8).sum()) for i in range(n_frames)]
     assert rows[:, 1].tolist() == exp
+
+
+def test_control_plane_is_gloo_and_leaves_stdout_clean(tmp_path):
+    """A bench line's consumer reads stdout as ONE JSON line: the gloo transport's connection chatter ("[Gloo] Rank 0 is
+    connected to ...", printed by its C++ side on file descriptor 1) must land on stderr.  Two fresh processes, as under the
+    launcher.  Also: the package's own backend choice is gloo even where GPUs exist -- no RCCL on the control plane."""
+    import subprocess
+    import sys
+    assert shard.CONTROL_BACKEND == "gloo"
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from bev_amd import shard\n"
+        "import torch.distributed as dist\n"
+        "r, _, w = shard.init()\n"
+        "assert dist.get_backend() == 'gloo'\n"
+        "shard.barrier(device_sync=False)\n"
+        "m = shard.max_over_ranks(float(r))\n"
+        "if r == 0:\n"
+        "    print(json.dumps({'max': m, 'world': w}), flush=True)\n"
+        "shard.barrier(device_sync=False)\n"
+        "dist.destroy_process_group()\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert outs[1][0].strip() == ""
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and "[Gloo]" not in outs[0][0]
+    import json
+    assert json.loads(lines[0]) == {"max": 1.0, "world": 2}

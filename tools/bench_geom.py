@@ -92,7 +92,7 @@ print(json.dumps({"config": "configs[4]: one 1080p -> 1024^2 uint8 bilinear warp
 
 # the same step captured once in a HIP graph and replayed (the launch-bound form a per-camera loop would run)
 try:
-    from bev_amd.graph import GraphedStep  # noqa: E402
+    from tools.graphed_step import GraphedStep  # noqa: E402
     kk[0] = 0
     g = GraphedStep(tracker_step)
     mean, mn = timeit(g.replay, n=100)
