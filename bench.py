@@ -53,7 +53,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec; ~5.0-6.3 TB/s streaming copy)
-KERNEL_SOURCES = ("bev_amd/csrc/warp_kernels.hip", "bev_amd/csrc/warp_kernels.h", "bev_amd/csrc/bevwarp_api.hip")
+
+
+def kernel_sources():
+    """Every source the warp kernels and their launch geometry are built from (bev_amd/csrc: *.hip, *.h, *.inc), sorted."""
+    d = os.path.join(ROOT, "bev_amd", "csrc")
+    return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".inc")) and not f.startswith("geom_")]
 
 
 def parse():
@@ -84,8 +89,8 @@ def parse():
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
+    for path in kernel_sources():
+        with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 

@@ -49,7 +49,7 @@ class BevWarpError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc the HIP sources into csrc/libbevwarp.so (gfx950)."""
-    cmd = ["make", "-C", _CSRC, "-j4"] + (["-B"] if force else [])
+    cmd = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(cmd, stdout=out)
     return LIB_PATH

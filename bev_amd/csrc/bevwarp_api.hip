@@ -159,12 +159,6 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     a.tile_h = rows_per_pass() * 4;
     while (a.tile_h > rows_per_pass() && per_row_of_tiles * ((dst_h + a.tile_h - 1) / a.tile_h) < resident) a.tile_h /= 2;
     if (dtype == BEVWARP_U8 && per_row_of_tiles * ((dst_h + 23) / 24) >= 2 * resident) a.tile_h = 24;
-#ifdef BEVWARP_TILE_H  // experiments only
-#if BEVWARP_TILE_H > 24
-#error "tiles of at most 24 rows (8-bit) / 16 rows (float): a wave keeps one LDS row per pass until the tile's stores"
-#endif
-    a.tile_h = (dtype == BEVWARP_U8 || BEVWARP_TILE_H <= 16) ? BEVWARP_TILE_H : 16;
-#endif
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
     a.tiles_per_frame = a.tiles_x * tiles_y;
@@ -179,9 +173,6 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // of 4); measured neutral to -2.5 % on footprints whose tiles cost alike, -8..-14 % on a perspective BEV from 12 frames up
     const int64_t round_per_xcd = resident / 8;
     a.tail_split = (a.tile_h % 8 == 0 && chunk >= 2 * round_per_xcd) ? (int)round_per_xcd : 0;
-#ifdef BEVWARP_TAIL_SPLIT  // experiments only
-    a.tail_split = chunk > BEVWARP_TAIL_SPLIT ? BEVWARP_TAIL_SPLIT : 0;
-#endif
     a.tpf_magic = div_magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
     a.tx_magic = div_magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
     a.bw0_magic = div_magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);

@@ -39,20 +39,14 @@ __device__ __forceinline__ void project_one(const H9& H, double x, double y, dou
     oy = tame ? Y * r : Y / Z;
 }
 
-#ifndef BEVWARP_PP_NT
-#define BEVWARP_PP_NT 1  // bit 0: non-temporal loads, bit 1: non-temporal stores.  A/B (tools/ab_points.py, profiles/r03_points_ab.txt): nt loads + plain stores is the fastest pair
-#endif
+// non-temporal loads + plain stores: the fastest of the four pairs (A/B: tools/ab_points.py, profiles/r03_points_ab.txt)
 template <typename V>
 __device__ __forceinline__ V pp_load(const V* p) {
-    if constexpr (BEVWARP_PP_NT & 1) return __builtin_nontemporal_load(p);
-    return *p;
+    return __builtin_nontemporal_load(p);
 }
 template <typename V>
 __device__ __forceinline__ void pp_store(const V& v, V* p) {
-    if constexpr (BEVWARP_PP_NT & 2)
-        __builtin_nontemporal_store(v, p);
-    else
-        *p = v;
+    *p = v;
 }
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 typedef double pf64x2 __attribute__((ext_vector_type(2)));

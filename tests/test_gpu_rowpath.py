@@ -351,7 +351,7 @@ def test_random_homographies_all_formats(W, seed):
 @pytest.mark.parametrize("interp", [0, 1])
 def test_row_affine_tiles_and_their_tolerance(W, dtype, interp):
     """Interior tiles whose source row and divide do not depend on the destination column take one reciprocal and one Y
-    coordinate per row segment (warp_kernels.hip, `tile_affine`).  Exact members of the class (M3 = M6 = 0: scale + shift,
+    coordinate per row segment (rows_tiles.inc, `tile_affine`).  Exact members of the class (M3 = M6 = 0: scale + shift,
     keystone), members up to floating-point noise, and matrices that cross the tolerance from below and from above -- all must
     equal the oracle; ties on X, on the uniform Y, and on both."""
     sw, sh, dw, dh = 700, 420, 512, 96

@@ -3,7 +3,8 @@
 
     python tools/ablate.py <name>=<spec>[+<spec>...] ...   ->  bev_amd/csrc/variants/<name>.so
 
-Each spec patches a COPY of warp_kernels.hip:
+Each spec patches a COPY of the kernel sources (bev_amd/csrc: warp_rows.h, rows_*.inc, coords.h, sample.h -- whichever file holds the
+snippet):
     nostore   store_s keeps its operands alive and returns
     noload    issue_s fabricates taps from the offsets (no vector memory loads)
     noblend   finish_s xors the taps instead of blending
@@ -25,11 +26,16 @@ CSRC = os.path.join(ROOT, "bev_amd", "csrc")
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-undefined-internal".split()
 
 
-def patch(src, spec):
+KERNEL_FILES = ("coords.h", "sample.h", "warp_rows.h", "rows_coords.inc", "rows_sample.inc", "rows_store.inc", "rows_tiles.inc", "warp_kernels.h")
+UNITS = ("warp_kernels", "warp_u8_linear", "warp_u8_nearest", "warp_f32_linear", "warp_f32_nearest", "warp_composite")
+
+
+def patch(files, spec):
+    """files: {name: text} of the kernel sources; the snippet is replaced (once) in the one file that holds it."""
     def rep(old, new):
-        nonlocal src
-        assert old in src, (spec, old[:60])
-        src = src.replace(old, new, 1)
+        hits = [n for n, t in files.items() if old in t]
+        assert len(hits) == 1, (spec, old[:60], hits)
+        files[hits[0]] = files[hits[0]].replace(old, new, 1)
     if spec == "nostore":
         rep("    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {  // xs = first pixel of the segment / block\n",
             "    auto store_s = [&](auto own, int xs, int y, const uint4 (&out)[NQ]) __attribute__((always_inline)) {\n"
@@ -104,29 +110,34 @@ def patch(src, spec):
         rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
     else:
         raise SystemExit("unknown spec " + spec)
-    return src
+    return files
 
 
 def main():
-    base = open(os.path.join(CSRC, "warp_kernels.hip")).read()
+    base = {n: open(os.path.join(CSRC, n)).read() for n in KERNEL_FILES}
     os.makedirs(os.path.join(CSRC, "variants"), exist_ok=True)
     procs = []
     for arg in sys.argv[1:]:
         name, specs = arg.split("=", 1)
-        src = base
+        files = dict(base)
         for spec in [s for s in specs.split("+") if s]:
-            src = patch(src, spec)
-        tmp = "/tmp/ablate_%s.hip" % name
-        open(tmp, "w").write(src)
-        obj = "/tmp/ablate_%s.o" % name
-        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", tmp, "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE)))
-    for name, obj, p in procs:
+            files = patch(files, spec)
+        tmp = "/tmp/ablate_%s" % name
+        os.makedirs(tmp, exist_ok=True)
+        for n, t in files.items():
+            open(os.path.join(tmp, n), "w").write(t)
+        for u in UNITS:  # the translation units themselves are never patched; they include the patched headers from tmp
+            open(os.path.join(tmp, u + ".hip"), "w").write(open(os.path.join(CSRC, u + ".hip")).read())
+            cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + tmp, "-c", os.path.join(tmp, u + ".hip"), "-o", os.path.join(tmp, u + ".o")]
+            procs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE)))
+    for name, p in procs:
         err = p.communicate()[1].decode()
         if p.returncode:
             raise SystemExit("%s: %s" % (name, err[-2000:]))
+    for arg in sys.argv[1:]:
+        name = arg.split("=", 1)[0]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", os.path.join(CSRC, "variants", name + ".so"),
-                               os.path.join(CSRC, "bevwarp_api.o"), obj, os.path.join(CSRC, "geom_kernels.o")])
+                               os.path.join(CSRC, "bevwarp_api.o"), os.path.join(CSRC, "geom_kernels.o")] + ["/tmp/ablate_%s/%s.o" % (name, u) for u in UNITS])
         print("built", name)
 
 

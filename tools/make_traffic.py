@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the committed rocprofv3 summaries (tools/prof.sh output copied to profiles/).
 HBM bytes per launch = FETCH_SIZE (KiB) x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB) x 1024."""
-import hashlib
 import json
 import os
 import re
@@ -10,11 +9,12 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # the kernel source the profiled library was built from: bench.py reports `traffic` only while it still matches
-h = hashlib.sha256()
-for rel in ("bev_amd/csrc/warp_kernels.hip", "bev_amd/csrc/warp_kernels.h", "bev_amd/csrc/bevwarp_api.hip"):
-    with open(os.path.join(root, rel), "rb") as f:
-        h.update(f.read())
-out = {"kernel_source_sha": h.hexdigest()[:16]}
+sys.path.insert(0, root)
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+_bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bench)
+out = {"kernel_source_sha": _bench.kernel_source_sha()}  # the same hash bench.py checks
 # keys as bench.py looks them up: <dtype>_<interp>[_<homography>]; files as tools/prof.sh tags them
 for key, tag in (("u8_linear", "u8_linear"), ("f32_linear", "f32_linear"), ("u8_nearest", "u8_nearest"), ("u8_linear_brno", "u8_brno"),
                  ("f32_linear_brno", "f32_brno"), ("u8_nearest_brno", "u8_nearest_brno")):
