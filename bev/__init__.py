@@ -19,16 +19,46 @@ __all__ = ["BEVWorldSpec", "Calib", "constructor"]
 
 # the sub-packages the reference's __init__ star-imports eagerly (they pull cv2, tqdm, ...): here they load on first use
 _LAZY = ("visualizer", "io", "converter", "tool", "evaluator", "tracker")
+# ... and the order in which it star-imports them (/root/reference/bev/__init__.py:1-6): a star-import binds every name of the
+# sub-package's __all__ -- sub-modules (bev.homo_constr, bev.homo_vis, bev.homo_io, bev.rbox_cvt, bev.io_vis, bev.compo, bev.kpts_eval)
+# and functions (bev.video_generator, bev.read_txt_to_dict, ...) -- as an attribute of `bev` itself
+_STAR = ("constructor", "visualizer", "io", "converter", "tool", "evaluator")
+_NOT_HERE = ("bev.%s is outside the MI355X hot path and comes from the reference's `bev` package: put the reference on sys.path "
+             "behind this overlay (python -m bev_amd.run does)")
+
+
+def _subpackage(name):
+    import importlib
+    try:
+        return importlib.import_module(__name__ + "." + name)
+    except ModuleNotFoundError as e:
+        if e.name != __name__ + "." + name:
+            raise  # the sub-package exists and one of ITS imports is missing (cv2, tqdm, ...): say so
+        return None
 
 
 def __getattr__(name):
     if name in _LAZY:
+        mod = _subpackage(name)
+        if mod is None:
+            raise AttributeError(_NOT_HERE % name)
+        return mod
+    if not name.startswith("__"):
+        # a name the reference's star-imports would have bound: look it up in the sub-packages' __all__, in the reference's order
         import importlib
-        try:
-            return importlib.import_module(__name__ + "." + name)
-        except ModuleNotFoundError as e:
-            if e.name != __name__ + "." + name:
-                raise
-            raise AttributeError("bev.%s is outside the MI355X hot path and comes from the reference's `bev` package: put the "
-                                 "reference on sys.path behind this overlay (python -m bev_amd.run does)" % name) from None
+        for sub in _STAR:
+            mod = _subpackage(sub)
+            if mod is None or name not in getattr(mod, "__all__", ()):
+                continue
+            if hasattr(mod, name):
+                value = getattr(mod, name)
+            else:  # a sub-module named in __all__: `from .sub import *` imports it
+                try:
+                    value = importlib.import_module(mod.__name__ + "." + name)
+                except ModuleNotFoundError as e:
+                    if e.name != mod.__name__ + "." + name:
+                        raise
+                    continue
+            globals()[name] = value
+            return value
     raise AttributeError("module %r has no attribute %r" % (__name__, name))

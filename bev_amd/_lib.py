@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("BEVWARP_LIB") or os.path.join(_CSRC, "libbevwarp.so")
 
 U8, F32, F64 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/bevwarp.h declares: (name, restype, argtypes)
 _c = ctypes

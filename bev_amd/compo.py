@@ -12,6 +12,7 @@ Both take numpy arrays or CUDA tensors (uint8, HWC).  Like the reference they re
 numpy; when any image is a tensor the result stays on the device.  Image paths are not accepted (the reference reads them
 with cv2.imread: decoding is outside this path).
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -68,12 +69,14 @@ def composite_reg_img(bg, fg, fg_mask, bw_mode=False, device="cuda"):
     return _result(out, as_numpy)
 
 
-_maps_cache = {}  # (matrix bytes, device) -> (device inverse maps, H_world2img_cam): a camera's calibration is static
+_maps_cache = collections.OrderedDict()  # (matrix bytes, device) -> (forward maps, H_world2img_cam), least recently used first
+_MAPS_MAX = 64
 
 
 def _composite_maps(H_world2bev, H_img2world_fix, K, RT, device):
     """The two inverse maps of compo.py:37-44 as one (2, 3, 3) device tensor, and H_world2img_cam (returned to the caller like
-    the reference does).  Cached by value: per call this is four small tobytes() instead of an inversion and an upload."""
+    the reference does).  Cached by value in two steps: the matrix algebra here (host), the inversion + upload in
+    bev_amd.warp.device_inverse."""
     mats = [np.ascontiguousarray(m, dtype=np.float64) for m in (H_world2bev, H_img2world_fix, K, RT)]
     key = (b"".join(m.tobytes() for m in mats), tuple(m.shape for m in mats), str(device))
     hit = _maps_cache.get(key)
@@ -82,12 +85,23 @@ def _composite_maps(H_world2bev, H_img2world_fix, K, RT, device):
         H_img2bev_fix = H_world2bev.dot(H_img2world_fix)
         H_world2img_cam = homo_from_KRt(K, Rt_homo=RT)
         H_img2bev_cam = H_world2bev.dot(np.linalg.inv(H_world2img_cam))
-        if len(_maps_cache) >= 64:
-            _maps_cache.clear()
-        hit = _maps_cache[key] = (device_inverse(np.stack([H_img2bev_fix, H_img2bev_cam]), device), H_world2img_cam)
-    elif hit[0].is_cuda:
-        hit[0].record_stream(torch.cuda.current_stream(hit[0].device))
-    return hit[0], hit[1].copy()
+        fwd = np.stack([H_img2bev_fix, H_img2bev_cam])
+        hit = _maps_cache[key] = [fwd, H_world2img_cam, device_inverse(fwd, device)]  # (device_inverse pins or refuses under capture)
+        while len(_maps_cache) > _MAPS_MAX:
+            _maps_cache.popitem(last=False)  # drops a reference only: a tensor a graph replays is held by device_inverse's pinned set
+    else:
+        _maps_cache.move_to_end(key)
+        capturing = False
+        if hit[2].is_cuda:
+            with torch.cuda.device(hit[2].device):
+                capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # a hipGraph capture bakes the tensor's ADDRESS into the graph: device_inverse's lifetime rules must see this use (it
+            # pins the entry for the life of the process, or raises when the matrices are no longer resident)
+            hit[2] = device_inverse(hit[0], device)
+        elif hit[2].is_cuda:
+            hit[2].record_stream(torch.cuda.current_stream(hit[2].device))
+    return hit[2], hit[1].copy()
 
 
 def composite_bev_img(bg, fg, fg_mask, H_world2bev, H_img2world_fix, K, RT, x_size, y_size, bw_mode=False, device="cuda"):

@@ -33,6 +33,23 @@ int block_width(int dst_w, int dst_h) {
     return bw0 < dst_w ? bw0 : dst_w;
 }
 
+// Does some byte of a strided source coincide with some byte of a strided destination?  The kernel reads taps of a frame while
+// other workgroups store: an in-place call would corrupt silently, so overlap is refused.  Bounding byte ranges first; when those
+// intersect but both sides walk their rows with ONE common stride S (equal row strides; frame strides multiples of S, or one
+// frame), every row of either side starts at a fixed residue mod S, and two regions of one allocation that lie side by side (the
+// left-half ROI of an image warped into its right half, say) are disjoint exactly when their residue intervals are.
+bool regions_overlap(uintptr_t s0, uint64_t s_row_bytes, int s_rows, int64_t s_rs, int64_t s_fs, uintptr_t d0, uint64_t d_row_bytes, int d_rows, int64_t d_rs,
+                     int64_t d_fs, int batch) {
+    const uintptr_t s1 = s0 + (uint64_t)(batch - 1) * s_fs + (uint64_t)(s_rows - 1) * s_rs + s_row_bytes;
+    const uintptr_t d1 = d0 + (uint64_t)(batch - 1) * d_fs + (uint64_t)(d_rows - 1) * d_rs + d_row_bytes;
+    if (!(s0 < d1 && d0 < s1)) return false;
+    if (s_rs == d_rs && s_rs > 0 && (batch == 1 || (s_fs % s_rs == 0 && d_fs % s_rs == 0)) && s_row_bytes + d_row_bytes <= (uint64_t)s_rs) {
+        const uint64_t S = (uint64_t)s_rs, a = s0 % S, b = d0 % S;
+        if ((b + S - a) % S >= s_row_bytes && (a + S - b) % S >= d_row_bytes) return false;  // column-disjoint: no row of one meets a row of the other
+    }
+    return true;
+}
+
 // division by invariants as a multiply-high; exact while n_max * d < 2^32, else the kernel divides
 uint32_t div_magic(uint64_t n_max, uint32_t d) { return (n_max * d < (1ull << 32) && d > 1) ? (uint32_t)((1ull << 32) / d) + 1u : 0u; }
 
@@ -55,6 +72,7 @@ const char* bevwarp_strerror(int status) {
         case BEVWARP_ERR_TOO_LARGE: return "source image side exceeds 32767 px, a row 16 MiB or a frame 2 GiB";
         case BEVWARP_ERR_NOT_FINITE: return "homography contains NaN or Inf";
         case BEVWARP_ERR_HIP: return "HIP runtime error (see bevwarp_last_hip_error)";
+        case BEVWARP_ERR_OVERLAP: return "source and destination overlap in memory (an in-place warp would read taps that other workgroups have already overwritten)";
         default: return "unknown status";
     }
 }
@@ -122,12 +140,14 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     if (src_w > 32767 || src_h > 32767) return BEVWARP_ERR_TOO_LARGE;
     if ((int64_t)src_h * src_row_stride >= ((int64_t)1 << 31) || src_row_stride >= (1 << 24)) return BEVWARP_ERR_TOO_LARGE;  // (kernels use 24-bit multiplies)
     if (batch == 0) return BEVWARP_OK;
-    {  // the kernel reads taps of a frame while other workgroups store into it: an in-place call would corrupt silently
+    if (po) {  // (float planes: bounding ranges only -- a frame's planes need not share the rows' stride)
         const uintptr_t s0 = (uintptr_t)src, s1 = s0 + (uint64_t)(batch - 1) * src_frame_stride + (uint64_t)(src_h - 1) * src_row_stride + (uint64_t)src_w * pix;
-        const uint64_t dst_frame_bytes = po ? (uint64_t)(channels - 1) * po->plane_stride + (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * 4
-                                            : (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * pix;
+        const uint64_t dst_frame_bytes = (uint64_t)(channels - 1) * po->plane_stride + (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * 4;
         const uintptr_t d0 = (uintptr_t)dst, d1 = d0 + (uint64_t)(batch - 1) * dst_frame_stride + dst_frame_bytes;
-        if (s0 < d1 && d0 < s1) return BEVWARP_ERR_BAD_ARG;
+        if (s0 < d1 && d0 < s1) return BEVWARP_ERR_OVERLAP;
+    } else if (regions_overlap((uintptr_t)src, (uint64_t)src_w * pix, src_h, src_row_stride, src_frame_stride, (uintptr_t)dst, (uint64_t)dst_w * pix, dst_h,
+                               dst_row_stride, dst_frame_stride, batch)) {
+        return BEVWARP_ERR_OVERLAP;
     }
 
     WarpArgs a;
@@ -245,12 +265,12 @@ int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_st
         (int64_t)fg_h * mask_row_stride >= ((int64_t)1 << 31))
         return BEVWARP_ERR_TOO_LARGE;  // (the kernel's 24-bit multiplies)
     {  // the destination must not overlap a source (as for bevwarp_warp)
-        const uintptr_t d0 = (uintptr_t)dst, d1 = d0 + (uint64_t)(dst_h - 1) * dst_row_stride + (uint64_t)dst_w * channels;
-        const uintptr_t s0[3] = {(uintptr_t)bg, (uintptr_t)fg, (uintptr_t)mask};
-        const uint64_t sz[3] = {(uint64_t)(bg_h - 1) * bg_row_stride + (uint64_t)bg_w * channels, (uint64_t)(fg_h - 1) * fg_row_stride + (uint64_t)fg_w * channels,
-                                (uint64_t)(fg_h - 1) * mask_row_stride + (uint64_t)fg_w * channels};
+        const void* sp[3] = {bg, fg, mask};
+        const int sh_[3] = {bg_h, fg_h, fg_h}, sw_[3] = {bg_w, fg_w, fg_w};
+        const int64_t srs_[3] = {bg_row_stride, fg_row_stride, mask_row_stride};
         for (int i = 0; i < 3; i++)
-            if (s0[i] < d1 && d0 < s0[i] + sz[i]) return BEVWARP_ERR_BAD_ARG;
+            if (regions_overlap((uintptr_t)sp[i], (uint64_t)sw_[i] * channels, sh_[i], srs_[i], 0, (uintptr_t)dst, (uint64_t)dst_w * channels, dst_h, dst_row_stride, 0, 1))
+                return BEVWARP_ERR_OVERLAP;
     }
     WarpArgs a;
     memset(&a, 0, sizeof(a));

@@ -72,11 +72,34 @@ def missing_name(modname, name, namespace):
     return AttributeError("module %r has no attribute %r" % (modname, name))
 
 
+def _swap_wh(boxes):
+    """[x, y, w, h, yaw, ...] rows -> [x, y, h, w, yaw]: the same rectangle turned a quarter about its own centre."""
+    if not hasattr(boxes, "dim"):  # (anything but a torch tensor: numpy semantics)
+        import numpy as np
+        boxes = np.asarray(boxes)
+    return boxes[:, [0, 1, 3, 2, 4]]
+
+
+def remove_d3d_stand_in():
+    """Take the stand-in out of sys.modules again (bev_amd.patch.uninstall); a real d3d is never touched."""
+    mod = sys.modules.get("d3d")
+    if mod is not None and getattr(mod, "__bev_amd_stand_in__", False):
+        sys.modules.pop("d3d", None)
+        sys.modules.pop("d3d.box", None)
+        return True
+    return False
+
+
 def ensure_d3d():
     """The reference's tracker imports `d3d` only for `d3d.box.box2d_iou(a, b, method="rbox")`
     (/root/reference/bev/tracker/rbox_tracker.py:40-47, :92), the call the HIP IoU kernel replaces.  When d3d is not
     installed, register a minimal module of that name whose `box.box2d_iou` is the HIP kernel, so the reference's file still
-    imports.  A real d3d is never touched."""
+    imports.  A real d3d is never touched.
+
+    Convention: the kernel (like bev.rbox) lays a box's length `h` along its yaw; the reference turns both yaws by pi/2 before it
+    calls d3d (rbox_tracker.py:88-91), i.e. d3d lays `w` along the yaw.  The stand-in therefore swaps w and h -- the exact form
+    of "yaw - pi/2" -- so that stand_in(a + pi/2, b + pi/2) == bev_amd.iou.iou_batch_rbox(a, b), the identity the rebound
+    tracker function relies on (d3d itself is absent here: its convention is assumed, parity unpinned)."""
     try:
         import d3d  # noqa: F401
         return False
@@ -90,7 +113,7 @@ def ensure_d3d():
     def box2d_iou(boxes1, boxes2, method="box"):
         if method != "rbox":
             raise NotImplementedError("bev_amd's d3d stand-in implements method='rbox' only")
-        return _iou.iou_any(boxes1, boxes2)
+        return _iou.iou_any(_swap_wh(boxes1), _swap_wh(boxes2))
 
     box.box2d_iou = box2d_iou
     d3d.box = box

@@ -107,7 +107,8 @@ def install(cv2_module=None, shim_missing_cv2=False, tracker=True, d3d_stand_in=
 
 
 def uninstall():
-    """Undo install(): the original cv2.warpPerspective and iou_batch_rbox are put back."""
+    """Undo install(): the original cv2.warpPerspective and iou_batch_rbox are put back, the d3d stand-in (if one was
+    registered) is removed from sys.modules."""
     if _state["cv2_registered"]:
         if sys.modules.get("cv2") is _state["cv2"]:
             del sys.modules["cv2"]
@@ -122,3 +123,5 @@ def uninstall():
         if _state["hook"] in sys.meta_path:
             sys.meta_path.remove(_state["hook"])
         _state["hook"] = None
+    from .overlay import remove_d3d_stand_in
+    remove_d3d_stand_in()  # (the restored iou_batch_rbox must not find the stand-in under d3d's name)

@@ -134,8 +134,10 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
         # whole Python layer is then one dictionary lookup and the C call with its argument tuple bound (a single 720p -> 512^2
         # frame is a 10-us kernel: the general path below costs more host time than that).
         try:
+            # (addresses can be recycled by the allocator: everything the slow path validates is part of the key -- dtypes and
+            # devices of all three tensors included, or a float32 / CPU matrix tensor at a recycled address would skip _check_minv)
             key = (src.data_ptr(), out.data_ptr(), M_inv_device.data_ptr(), src.shape, src.stride(), out.shape, out.stride(), M_inv_device.shape,
-                   M_inv_device.stride(), src.dtype, out.dtype, dsize[0], dsize[1], flags)
+                   M_inv_device.stride(), src.dtype, out.dtype, M_inv_device.dtype, src.device, out.device, M_inv_device.device, dsize[0], dsize[1], flags)
             plan = _plans.get(key)
         except (AttributeError, TypeError, IndexError):
             plan = None

@@ -47,15 +47,16 @@
 extern "C" {
 #endif
 
-#define BEVWARP_ABI_VERSION 4
+#define BEVWARP_ABI_VERSION 5
 
 typedef enum bevwarp_status {
     BEVWARP_OK = 0,
-    BEVWARP_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, misaligned or overlapping strides */
+    BEVWARP_ERR_BAD_ARG = -1,      /* NULL pointer, non-positive size, misaligned stride                 */
     BEVWARP_ERR_UNSUPPORTED = -2,  /* dtype / channel count / interpolation outside the supported set    */
     BEVWARP_ERR_TOO_LARGE = -3,    /* source side > 32767 px (fixed-point map range), a source row >= 16 MiB or frame >= 2 GiB */
     BEVWARP_ERR_NOT_FINITE = -4,   /* homography contains NaN / Inf                                      */
-    BEVWARP_ERR_HIP = -5           /* a HIP runtime call failed; see bevwarp_last_hip_error()            */
+    BEVWARP_ERR_HIP = -5,          /* a HIP runtime call failed; see bevwarp_last_hip_error()            */
+    BEVWARP_ERR_OVERLAP = -6       /* source and destination share bytes (ABI v5; v4 reported BAD_ARG)   */
 } bevwarp_status;
 
 typedef enum bevwarp_dtype { BEVWARP_U8 = 0, BEVWARP_F32 = 1, BEVWARP_F64 = 2 } bevwarp_dtype;
@@ -77,9 +78,12 @@ int bevwarp_invert_homography(const double *M_fwd /*HOST*/, double *M_inv /*HOST
  * dst[b] = warpPerspective(src[b], M[b], (dst_w, dst_h)) for b in [0, batch), BORDER_CONSTANT.
  *
  *   src, dst       device; `channels` interleaved values of `dtype` (BEVWARP_U8 | BEVWARP_F32) per pixel.
- *                  src and dst must not overlap: the call returns BEVWARP_ERR_BAD_ARG when the byte ranges
- *                  [src, last byte of frame batch-1] and [dst, last byte of frame batch-1] intersect (an
- *                  in-place warp would read taps other workgroups have already overwritten).
+ *                  src and dst must not overlap (an in-place warp would read taps other workgroups have already
+ *                  overwritten): the call returns BEVWARP_ERR_OVERLAP when the byte ranges [src, last byte of
+ *                  frame batch-1] and [dst, last byte of frame batch-1] intersect -- unless both walk their rows
+ *                  with one common stride (equal row strides, frame strides multiples of it) and their rows
+ *                  occupy disjoint byte columns of that stride: two ROIs of one image that lie side by side are
+ *                  accepted, as cv2.warpPerspective accepts them.
  *                  "each tap outside replaced by the border value": a pixel whose four taps are ALL outside
  *                  is the border value itself (float32 too), as in OpenCV's remapBilinear.
  *   *_frame_stride bytes between consecutive frames; *_row_stride bytes between rows (>= row bytes).
@@ -104,7 +108,7 @@ int bevwarp_warp(const void *src, void *dst, int batch, int src_h, int src_w, in
  *   dst             device float32; dst_plane_stride bytes between channel planes, dst_row_stride between rows,
  *                   dst_frame_stride between frames (all multiples of 4; multiples of 16 enable the wide stores).
  *   scale, bias     HOST, `channels` doubles each (converted to float32); NULL = 1 and 0.
- * Overlap of src and dst: as for bevwarp_warp (BEVWARP_ERR_BAD_ARG).
+ * Overlap of src and dst: BEVWARP_ERR_OVERLAP when the bounding byte ranges intersect.
  */
 int bevwarp_warp_planar(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_plane_stride,
@@ -128,7 +132,7 @@ int bevwarp_composite(const void *bg, const void *fg, const void *mask, void *ou
  *   M_inv_bg, M_inv_cam: device, 9 float64 each, INVERSE maps (dst px -> bg px / camera px).
  *   fg_gray: non-zero = the reference's bw_mode (compo.py:13-14): the foreground is converted BGR -> grey -> BGR before it is
  *            warped, i.e. tap by tap ((1868 B + 9617 G + 4899 R + 8192) >> 14, OpenCV's 8-bit form); channels must be 3.
- * Overlap of dst with a source: BEVWARP_ERR_BAD_ARG.
+ * Overlap of dst with a source: BEVWARP_ERR_OVERLAP (same rule as bevwarp_warp).
  */
 int bevwarp_warp_composite(const void *bg, int bg_h, int bg_w, int64_t bg_row_stride, const void *fg, const void *mask,
                            int fg_h, int fg_w, int64_t fg_row_stride, int64_t mask_row_stride, void *dst, int dst_h,

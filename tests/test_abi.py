@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert getattr(raw, n) is not None
-    assert lib.bevwarp_version() == _lib.ABI_VERSION == 4
+    assert lib.bevwarp_version() == _lib.ABI_VERSION == 5
 
 
 def test_header_cites_the_reference_interfaces():
@@ -46,7 +46,7 @@ def test_header_cites_the_reference_interfaces():
 
 def test_strerror_and_argument_validation_without_a_device(lib):
     assert lib.bevwarp_strerror(0) == b"ok"
-    for code in (-1, -2, -3, -4, -5):
+    for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.bevwarp_strerror(code)) > 4
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
     warp = lib.bevwarp_warp
@@ -69,14 +69,25 @@ def test_strerror_and_argument_validation_without_a_device(lib):
     assert call(a4=40000, a9=120000, a8=960000) == -3  # source wider than 32767
     assert call(a2=0) == 0              # empty batch is a no-op
     # src and dst must not overlap (include/bevwarp.h): in place, partially, and batch-wise through the frame strides
-    assert call(a1=one) == -1
-    assert call(a1=ctypes.c_void_p(16 + 191)) == -1          # the last source byte
+    nan_border = ctypes.cast((ctypes.c_double * 3)(0.0, float("nan"), 0.0), ctypes.c_void_p)  # (a call that passes the overlap test fails later, on this)
+    assert b"overlap" in lib.bevwarp_strerror(-6)
+    assert call(a1=one) == -6
+    assert call(a1=ctypes.c_void_p(16 + 191)) == -6          # the last source byte
     assert call(a1=ctypes.c_void_p(16 + 192), a16=ctypes.cast((ctypes.c_double * 3)(0.0, float("nan"), 0.0), ctypes.c_void_p)) == -4  # adjacent is fine (fails later, on the border)
-    assert call(a2=4, a1=ctypes.c_void_p(16 + 3 * 192 + 100)) == -1   # inside frame 3 of a 4-frame source
-    assert call(a2=4, a0=ctypes.c_void_p((1 << 20) + 3 * 192 + 191)) == -1  # source starting on the last byte of destination frame 3
+    assert call(a2=4, a1=ctypes.c_void_p(16 + 3 * 192 + 100)) == -6   # inside frame 3 of a 4-frame source
+    assert call(a2=4, a0=ctypes.c_void_p((1 << 20) + 3 * 192 + 191)) == -6  # source starting on the last byte of destination frame 3
+    # two ROIs of ONE image side by side (equal row strides, disjoint byte columns): accepted, as cv2.warpPerspective accepts them --
+    # an 8 x 8 RGB source at column 0 and an 8 x 8 destination at column 8 of a 16-pixel-wide image (row stride 48)
+    base = 4096
+    assert call(a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=48, a8=384, a10=384, a16=nan_border) == -4
+    assert call(a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 23), a9=48, a11=48, a8=384, a10=384, a16=nan_border) == -6  # one byte column shared
+    assert call(a0=ctypes.c_void_p(base + 24), a1=ctypes.c_void_p(base), a9=48, a11=48, a8=384, a10=384, a16=nan_border) == -4  # right half into left half
+    assert call(a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=52, a8=384, a10=416, a16=nan_border) == -6  # different strides: conservative
+    assert call(a2=3, a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=48, a8=384, a10=384, a16=nan_border) == -4  # batched, frame strides multiples of 48
+    assert call(a2=3, a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=48, a8=400, a10=384, a16=nan_border) == -6
     planar = lib.bevwarp_warp_planar
     pargs = [one, ctypes.c_void_p(16 + 100), 1, 8, 8, 8, 8, 3, 192, 24, 768, 256, 32, one, 1, _lib.U8, 1, None, None, None, None]
-    assert planar(*pargs) == -1
+    assert planar(*pargs) == -6
     bad_border = (ctypes.c_double * 3)(0.0, float("nan"), 0.0)
     assert call(a16=ctypes.cast(bad_border, ctypes.c_void_p)) == -4
     H = (ctypes.c_double * 9)(*[float("inf")] * 9)

@@ -451,3 +451,29 @@ def test_the_reference_sort_loads_through_the_overlay_with_the_hip_iou_bound(tmp
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     assert rep["Sort"] == "bev.tracker.rbox_tracker" and rep["file"] == os.path.join(REFERENCE, "bev", "tracker", "rbox_tracker.py") and rep["err"] == "None"
     assert rep["iou"] == "bev_amd.iou"
+
+
+def test_star_exported_names_resolve_through_the_overlay(tmp_path, golden):
+    """names the reference's `from .io import *` / `from .visualizer import *` bind on `bev` (bev.video_generator,
+    bev.homo_vis, bev.kpts_eval, ...) must be readable as attributes of the overlay package too."""
+    stubs, ref, _ = build_stubs(tmp_path, golden)
+    code = textwrap.dedent('''
+        import json
+        import bev
+        rep = {"video_generator": bev.video_generator.__module__, "homo_vis": bev.homo_vis.__name__, "kpts_eval": bev.kpts_eval.__name__,
+               "homo_constr": bev.homo_constr.load_calib.__module__, "init_ran": hasattr(bev, "REFERENCE_INIT_RAN"), "bev_file": bev.__file__}
+        try:
+            bev.nothing_of_the_kind
+            rep["missing"] = "no error"
+        except AttributeError:
+            rep["missing"] = "AttributeError"
+        print(json.dumps(rep))
+    ''')
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, str(stubs), str(ref)])  # overlay first, the (stub) reference behind it
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["video_generator"] == "bev.io.utils" and rep["homo_vis"] == "bev.visualizer.homo_vis" and rep["kpts_eval"] == "bev.evaluator.kpts_eval"
+    assert rep["homo_constr"] == "bev_amd.constructor.homo_constr"  # a star-exported name the overlay owns stays ours
+    assert not rep["init_ran"] and os.path.samefile(rep["bev_file"], os.path.join(ROOT, "bev", "__init__.py")) and rep["missing"] == "AttributeError"

@@ -342,3 +342,64 @@ def test_warp_composite_every_channel_count(c):
     if c != 3:
         with pytest.raises(ValueError):
             composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, Ks, RT, dw, dh, bw_mode=True)
+
+
+def test_d3d_stand_in_identity_on_the_device():
+    """ADVICE r03 (GPU twin of tests/test_host_api.py::test_d3d_stand_in_is_consistent_with_the_rebound_tracker_iou): through
+    the HIP kernel, stand_in(a + pi/2, b + pi/2) == iou_batch_rbox(a, b) on non-square boxes."""
+    import sys
+
+    from bev_amd import overlay
+    from bev_amd.iou import iou_batch_rbox
+    saved = {k: sys.modules.pop(k) for k in ("d3d", "d3d.box") if k in sys.modules}
+    try:
+        if not overlay.ensure_d3d():
+            pytest.skip("a real d3d is installed")
+        import d3d
+        rng = np.random.default_rng(4)
+        a = np.column_stack([rng.uniform(0, 12, (40, 2)), rng.uniform(1, 2, 40), rng.uniform(3, 6, 40), rng.uniform(-np.pi, np.pi, 40)])
+        b = np.column_stack([rng.uniform(0, 12, (30, 2)), rng.uniform(1, 2, 30), rng.uniform(3, 6, 30), rng.uniform(-np.pi, np.pi, 30)])
+        turn = np.array([0, 0, 0, 0, np.pi / 2])
+        want = iou_batch_rbox(a, b)
+        np.testing.assert_allclose(want, co.rbox_iou(a, b), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(d3d.box.box2d_iou(a + turn, b + turn, method="rbox"), want, rtol=0, atol=1e-12)
+        ta, tb = torch.from_numpy(a + turn).cuda(), torch.from_numpy(b + turn).cuda()  # tensors in, a tensor on the same device out
+        got = d3d.box.box2d_iou(ta, tb, method="rbox")
+        assert got.is_cuda
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-12)
+    finally:
+        overlay.remove_d3d_stand_in()
+        sys.modules.update(saved)
+
+
+def test_composite_maps_survive_cache_churn_under_a_captured_graph():
+    """composite_bev_img captured into a hipGraph AFTER an eager call (so the capture finds its maps cached) must pin
+    them: churning both caches afterwards must not free the address the graph replays."""
+    from bev_amd import compo, warp as W
+    from bev_amd.homo import homo_from_KRt
+    from tests import workloads as wl
+    from tools.graphed_step import GraphedStep
+    K = np.array([[400.0, 0, 159.0], [0, 395.0, 88.5], [0, 0, 1.0]])
+    cth, sth = np.cos(0.8), np.sin(0.8)
+    RT = np.array([[1, 0, 0, 0.0], [0, cth, -sth, 2.0], [0, sth, cth, 14.0], [0, 0, 0, 1.0]])
+    H_world2bev = np.array([[0.0, 14.0, 250.0], [-14.0, 0.0, 60.0], [0.0, 0.0, 1.0]])
+    H_img2world_fix = np.linalg.inv(homo_from_KRt(K, Rt_homo=RT)) @ np.array([[1, 0, 2.0], [0, 1, -1.0], [0, 0, 1]])
+    bg, fg, mask = (torch.from_numpy(wl.frame(90 + i, 180, 320, np.uint8)).cuda() for i in range(3))
+    eager, _ = compo.composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 256, 128)  # eager first: the maps are cached, not pinned
+    holder = {}
+
+    def step():
+        holder["out"], _ = compo.composite_bev_img(bg, fg, mask, H_world2bev, H_img2world_fix, K, RT, 256, 128)
+        return holder["out"]
+
+    g = GraphedStep(step)
+    # churn: evict everything evictable from both caches and let the allocator reuse what was freed
+    for i in range(max(W._MINV_CACHE_MAX, compo._MAPS_MAX) + 8):
+        Hs = H_world2bev + np.array([[0, 0, float(i + 1)], [0, 0, 0], [0, 0, 0]])
+        compo._composite_maps(Hs, H_img2world_fix, K, RT, bg.device)
+    junk = [torch.full((2, 3, 3), float("nan"), dtype=torch.float64, device="cuda") for _ in range(512)]
+    torch.cuda.synchronize()
+    out = g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    del junk

@@ -309,3 +309,59 @@ def test_config4_full_per_gpu_shard_properties(W):
         assert torch.equal(crop, frames[:, :dh, :dw])
     del frames, out, out_p, crop
     torch.cuda.empty_cache()
+
+
+def test_side_by_side_rois_of_one_image(W):
+    """warping the left-half ROI of an image into its right-half ROI (equal row strides, disjoint byte columns) is a
+    call cv2.warpPerspective accepts; the overlap guard must not refuse it -- and must still refuse ROIs that share a column,
+    with a message that names the overlap."""
+    h, w = 240, 512
+    for dtype in (np.uint8, np.float32):
+        img = wl.frame(11, h, w, dtype)
+        big = torch.from_numpy(img).cuda()
+        left, right = big[:, :w // 2], big[:, w // 2:]
+        M = wl.keystone_H(w // 2, h, w // 2, h)
+        exp = co.warp_perspective(np.ascontiguousarray(img[:, :w // 2]), M, (w // 2, h))
+        out = W.warp_perspective(left, M, (w // 2, h), out=right)
+        torch.cuda.synchronize()
+        assert out is right
+        check(big[:, w // 2:].cpu().numpy(), exp)
+        np.testing.assert_array_equal(big[:, :w // 2].cpu().numpy(), img[:, :w // 2])  # the source half is untouched
+        with pytest.raises(ValueError, match="overlap"):
+            W.warp_perspective(left, M, (w // 2, h), out=big[:, w // 2 - 1:w - 1])
+        with pytest.raises(ValueError, match="overlap"):
+            W.warp_perspective(big, np.eye(3), (w, h), out=big)
+
+
+def test_validated_launch_cache_hits_and_misses(W):
+    """ADVICE r03: the plan cache of warp_perspective (bev_amd/warp.py::_plans).  A second identical call takes the cached
+    launch and equals the oracle; a matrix tensor of another dtype or on another device -- the allocator can hand a recycled
+    address to either -- must still run into the slow path's validation; the cache clears itself at _PLANS_MAX."""
+    sw, sh, dw, dh = 320, 180, 128, 96
+    M = wl.synth_brno_H(sw, sh, dw, dh)
+    f0, f1 = wl.frame(1, sh, sw, np.uint8), wl.frame(2, sh, sw, np.uint8)
+    src, out = torch.from_numpy(f0).cuda(), torch.empty((dh, dw, 3), dtype=torch.uint8, device="cuda")
+    minv = W.device_inverse(M, src.device)
+    W._plans.clear()
+    W.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv)
+    assert len(W._plans) == 1
+    src.copy_(torch.from_numpy(f1).cuda())
+    W.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv)  # the hit: same buffers, new pixels
+    torch.cuda.synchronize()
+    assert len(W._plans) == 1
+    check(out.cpu().numpy(), co.warp_perspective(f1, M, (dw, dh)))
+    # same shape and strides, other dtype: 36-byte matrices must not be read as 72-byte ones
+    with pytest.raises(ValueError):
+        W.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv.to(torch.float32))
+    with pytest.raises(ValueError):
+        W.warp_perspective(src, None, (dw, dh), out=out, M_inv_device=minv.cpu())
+    # a key that differs only in the matrix tensor's dtype is a different key even at the same address (simulated: the real
+    # thing needs the allocator to recycle the block)
+    (key, plan), = list(W._plans.items())
+    assert torch.float64 in key and src.device in key
+    # the cache empties itself rather than grow without bound
+    for i in range(W._PLANS_MAX + 3):
+        W._plans[("filler", i)] = plan
+    W.warp_perspective(src, None, (dw, dh), out=torch.empty_like(out), M_inv_device=minv)
+    assert len(W._plans) <= 4
+    W._plans.clear()

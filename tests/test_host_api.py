@@ -382,3 +382,66 @@ def test_composite_integer_form_equals_the_float64_expression():
     fi, bi, mi = (np.arange(256, dtype=np.int64).reshape(s) for s in ((256, 1, 1), (1, 256, 1), (1, 1, 256)))
     got = ((fi * mi + bi * (255 - mi) + 127) * 0x8081) >> 23
     np.testing.assert_array_equal(got, ref.astype(np.int64))
+
+
+def test_d3d_stand_in_is_consistent_with_the_rebound_tracker_iou(monkeypatch):
+    """the reference calls d3d.box.box2d_iou(a + pi/2, b + pi/2) (rbox_tracker.py:88-92) and the rebound
+    iou_batch_rbox calls the kernel with the yaws as given, so the d3d stand-in must satisfy
+    stand_in(a + pi/2, b + pi/2) == iou_batch_rbox(a, b): it swaps w and h.  Checked here with the CPU oracle standing in for
+    the kernel (the GPU twin is tests/test_gpu_geom.py::test_d3d_stand_in_identity_on_the_device), on non-square boxes --
+    turning a box a quarter about its own centre changes the IoU: two 1 x 4 boxes at (0, 0) and (0, 1) give 0 one way, 0.6 the other."""
+    import sys
+
+    from oracle import cpu_oracle as co
+
+    from bev_amd import iou as iou_mod
+    from bev_amd import overlay
+    monkeypatch.setattr(iou_mod, "iou_any", lambda a, b, device="cuda": co.rbox_iou(np.asarray(a, dtype=np.float64)[:, :5], np.asarray(b, dtype=np.float64)[:, :5]))
+    saved = {k: sys.modules.pop(k) for k in ("d3d", "d3d.box") if k in sys.modules}
+    try:
+        if not overlay.ensure_d3d():
+            pytest.skip("a real d3d is installed: the stand-in is not registered")
+        import d3d
+        rng = np.random.default_rng(4)
+        a = np.column_stack([rng.uniform(0, 12, (40, 2)), rng.uniform(1, 2, 40), rng.uniform(3, 6, 40), rng.uniform(-np.pi, np.pi, 40)])
+        b = np.column_stack([rng.uniform(0, 12, (30, 2)), rng.uniform(1, 2, 30), rng.uniform(3, 6, 30), rng.uniform(-np.pi, np.pi, 30)])
+        turn = np.array([0, 0, 0, 0, np.pi / 2])
+        want = co.rbox_iou(a, b)  # what bev_amd.iou.iou_batch_rbox computes (kernel convention: h along the yaw)
+        assert (want > 0.05).sum() > 10
+        np.testing.assert_allclose(d3d.box.box2d_iou(a + turn, b + turn, method="rbox"), want, rtol=0, atol=1e-12)
+        # the advisor's example: under d3d's convention (w along the yaw) two 1 x 4 boxes one unit apart across their length overlap 3/5
+        two = np.array([[0.0, 0.0, 4.0, 1.0, 0.0], [1.0, 0.0, 4.0, 1.0, 0.0]])
+        np.testing.assert_allclose(d3d.box.box2d_iou(two[:1], two[1:], method="rbox"), [[0.6]], atol=1e-12)
+        np.testing.assert_allclose(co.rbox_iou(two[:1], two[1:]), [[0.0]], atol=1e-12)  # ... and not at all with h along the yaw
+        with pytest.raises(NotImplementedError):
+            d3d.box.box2d_iou(a, b)
+        assert overlay.remove_d3d_stand_in() and "d3d" not in sys.modules and not overlay.remove_d3d_stand_in()
+    finally:
+        sys.modules.pop("d3d", None)
+        sys.modules.pop("d3d.box", None)
+        sys.modules.update(saved)
+
+
+def test_patch_uninstall_removes_the_d3d_stand_in():
+    import sys
+
+    from bev_amd import overlay, patch
+    saved = {k: sys.modules.pop(k) for k in ("d3d", "d3d.box") if k in sys.modules}
+    try:
+        if not overlay.ensure_d3d():
+            pytest.skip("a real d3d is installed")
+        assert getattr(sys.modules["d3d"], "__bev_amd_stand_in__", False)
+        patch.uninstall()
+        assert "d3d" not in sys.modules and "d3d.box" not in sys.modules
+    finally:
+        sys.modules.update(saved)
+
+
+def test_bev_serves_the_names_the_reference_star_imports():
+    """/root/reference/bev/__init__.py:1-6 star-imports six sub-packages, which binds every name of their __all__ on `bev`
+    itself.  The overlay resolves those lazily: the ones it owns here, the rest from a co-installed reference."""
+    import bev
+    assert bev.homo_constr.__name__ == "bev.constructor.homo_constr" and bev.compo.__name__ == "bev.tool.compo"
+    assert "homo_constr" in vars(bev)  # cached after the first lookup
+    with pytest.raises(AttributeError):
+        bev.no_such_name
