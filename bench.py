@@ -250,7 +250,7 @@ def kernel_clock(w, launches=300):
     dbg = lib.bevwarp_debug_clock
     dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
     esz, stream = w.esz, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    out4 = (ctypes.c_ulonglong * 4)()
+    out4 = (ctypes.c_ulonglong * 16)()  # (16 words: csrc/warp_rows.h kClkWords; [0..2] = shader ticks, 100-MHz ticks, workgroups)
 
     def run(n):
         for i in range(n):

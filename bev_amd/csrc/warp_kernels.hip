@@ -45,7 +45,7 @@ __global__ void footprint_kernel(unsigned char* __restrict__ touched, int batch,
 hipError_t launch_u8_linear_clock(unsigned long long*, int), launch_u8_nearest_clock(unsigned long long*, int), launch_f32_linear_clock(unsigned long long*, int),
     launch_f32_nearest_clock(unsigned long long*, int), launch_composite_clock(unsigned long long*, int);
 hipError_t debug_read_clock(unsigned long long* out4, int reset) {  // the sum over the translation units
-    for (int i = 0; i < 4; i++) out4[i] = 0;
+    for (int i = 0; i < 16; i++) out4[i] = 0;  // (16 words: warp_rows.h, kClkWords)
     for (auto fn : {launch_u8_linear_clock, launch_u8_nearest_clock, launch_f32_linear_clock, launch_f32_nearest_clock, launch_composite_clock}) {
         const hipError_t e = fn(out4, reset);
         if (e != hipSuccess) return e;

@@ -48,7 +48,8 @@ namespace {
 // kernels of that build are named warp_rows_clockbuild, so that a kernel trace of bench.py does not mix them with the product's.
 #ifdef BEVWARP_CLOCK
 #define warp_rows warp_rows_clockbuild
-static __device__ unsigned long long g_clk[4];
+constexpr int kClkWords = 16;  // [0..2] shader ticks, 100-MHz ticks, workgroups; [4..11] per-role stamps of staged tiles (rows_staged.inc)
+static __device__ unsigned long long g_clk[kClkWords];
 #endif
 // NSRC = 3 is warp_composite (bev/tool/compo.py:26-49) in one launch: a workgroup of 12 waves, four per source -- waves 0-3
 // warp the background, 4-7 the foreground, 8-11 its mask, each group exactly as a workgroup of the plain kernel would, every
@@ -85,7 +86,20 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // loses 13 us of 75 (ablations: profiles/r03_tables.txt).  Stored at the end of the tile, nothing waits behind them.
     // (composite: one row, its passes go to the LDS tiles at once.)
     constexpr int kRowsLds = NSRC > 1 ? 1 : (sizeof(T) == 1 ? 6 : 4);  // passes of a wave over the tallest tile (24 / 16 rows)
-    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kWaves * NSRC][kRowsLds][TRW];
+    // STAGED tiles (rows_staged.inc): one producer wave copies the tile's source rows into a ring of LDS slots with coalesced LDS-DMA
+    // loads, three consumer waves read their taps from the ring.  The ring, two transposition rows per consumer and the four
+    // hand-off words share the LDS of the deferred-store rows (a tile is processed one way or the other).
+    constexpr bool kStageable = NSRC == 1 && INTERP == kLinear && C == 3 && (sizeof(T) == 4 || RS4);
+    constexpr int kCons = kWaves - 1;                       // consumer waves of a staged tile
+    constexpr int kRing = sizeof(T) == 1 ? 16 : 10;         // source rows the ring holds
+    constexpr int kFlight = sizeof(T) == 1 ? 12 : 6;        // rows the producer keeps in flight (<= kRing - 2, rows_staged.inc)
+    constexpr int kSlot = sizeof(T) == 1 ? 1536 : 3072;     // bytes of one slot: the widest row span a staged tile may have
+    constexpr int kStageTr = 2 * TRW * 4;                   // bytes of a consumer's two transposition rows
+    constexpr int kStageFlagOff = kRing * kSlot + kCons * kStageTr;
+    constexpr int kStageAux = 0;                            // cache policy of the ring fills (0: default, 2: nt)
+    constexpr int kTrDwords = kWaves * NSRC * kRowsLds * TRW;
+    constexpr int kLdsDwords = kStageable && (kStageFlagOff + 16) / 4 > kTrDwords ? (kStageFlagOff + 16) / 4 : kTrDwords;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kLdsDwords];
     // (composite only) the warped tiles, one packed pixel per dword: [source][row of the tile][pixel]
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[NSRC > 1 ? NSRC * kCompositeRows * TW : 4];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
@@ -162,6 +176,8 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
 #include "rows_sample.inc"
 #include "rows_store.inc"
 #include "rows_tiles.inc"
+#include "rows_staged.inc"
+#include "rows_run.inc"
     if constexpr (NSRC > 1) {
         // -- composite_reg_img (bev/tool/compo.py:16-23) on the three LDS tiles.  The reference evaluates
         //   round(fg * (m / 255) + bg * (1 - m / 255)) in float64 and clips to 255; with N = fg m + bg (255 - m) that value is N / 255
@@ -241,13 +257,13 @@ void launch_channels(const WarpArgs& a, int channels, dim3 grid, hipStream_t str
 }
 
 #ifdef BEVWARP_CLOCK
-inline hipError_t read_clock_of_this_unit(unsigned long long* out4, int reset) {  // out4 += this translation unit's counters
-    unsigned long long v[4];
+inline hipError_t read_clock_of_this_unit(unsigned long long* out16, int reset) {  // out16 += this translation unit's counters
+    unsigned long long v[kClkWords];
     hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clk), sizeof(v));
     if (e != hipSuccess) return e;
-    for (int i = 0; i < 4; i++) out4[i] += v[i];
+    for (int i = 0; i < kClkWords; i++) out16[i] += v[i];
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
+        unsigned long long z[kClkWords] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
     }
     return e;

@@ -16,6 +16,9 @@ snippet):
     noedge    EDGE blocks cost what OUT blocks cost
     ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
+    nostage   no tile takes the LDS-staged producer / consumer form (rows_staged.inc): the gather pipelines only
+    stagent   the staged form's ring fills are non-temporal (aux = 2)
+    ring16 / ring4   the staged form's ring holds 16 / 4 source rows instead of 8
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
 import subprocess
@@ -26,7 +29,7 @@ CSRC = os.path.join(ROOT, "bev_amd", "csrc")
 FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-undefined-internal".split()
 
 
-KERNEL_FILES = ("coords.h", "sample.h", "warp_rows.h", "rows_coords.inc", "rows_sample.inc", "rows_store.inc", "rows_tiles.inc", "warp_kernels.h")
+KERNEL_FILES = ("coords.h", "sample.h", "warp_rows.h", "rows_coords.inc", "rows_sample.inc", "rows_store.inc", "rows_tiles.inc", "rows_staged.inc", "rows_run.inc", "warp_kernels.h")
 UNITS = ("warp_kernels", "warp_u8_linear", "warp_u8_nearest", "warp_f32_linear", "warp_f32_nearest", "warp_composite")
 
 
@@ -108,6 +111,12 @@ def patch(files, spec):
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || tile_in) {")
     elif spec == "ownblk":  # interior tiles: blocks whatever the slant
         rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
+    elif spec == "nostage":
+        rep("    constexpr bool kStageable = NSRC == 1 && INTERP == kLinear && C == 3 && (sizeof(T) == 4 || RS4);", "    constexpr bool kStageable = false;")
+    elif spec == "stagent":
+        rep("    constexpr int kStageAux = 0; ", "    constexpr int kStageAux = 2; ")
+    elif spec in ("ring16", "ring4"):
+        raise SystemExit("ring specs are gone: kRing, kFlight are per-format constants of warp_rows.h")
     else:
         raise SystemExit("unknown spec " + spec)
     return files

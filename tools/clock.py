@@ -44,7 +44,7 @@ while time.time() < t_end:
         warp.warp_perspective(srcs[n % 4], None, (dw, dh), flags=flags, out=dsts[n % 4], M_inv_device=minv)
         n += 1
     torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 4)()
+out = (ctypes.c_ulonglong * 16)()
 assert dbg(out, 1) == 0
 for _ in range(20):
     warp.warp_perspective(srcs[n % 4], None, (dw, dh), flags=flags, out=dsts[n % 4], M_inv_device=minv)
@@ -53,3 +53,8 @@ torch.cuda.synchronize()
 assert dbg(out, 0) == 0
 print("%s %s %s: %d workgroups, mean life %.0f shader ticks = %.2f us, clock held %.0f MHz" % (
     args.dtype, args.interp, args.homography, out[2], out[0] / out[2], out[1] / out[2] / 100.0, 100.0 * out[0] / out[1]))
+if out[7]:  # staged tiles ran (rows_staged.inc): per-role stamps, shader ticks
+    P, C = out[7], out[7] * 3
+    print("staged tiles %d: producer life %.0f ticks (waiting for a free slot %.0f, for rows to land %.0f); consumer life %.0f ticks, %.1f rows each "
+          "(waiting for source rows %.0f, of which before its first row %.0f)" % (
+              P, out[4] / P, out[5] / P, out[6] / P, out[8] / C, out[11] / C, out[9] / C, out[10] / C))
