@@ -48,8 +48,14 @@ namespace {
 // kernels of that build are named warp_rows_clockbuild, so that a kernel trace of bench.py does not mix them with the product's.
 #ifdef BEVWARP_CLOCK
 #define warp_rows warp_rows_clockbuild
-constexpr int kClkWords = 16;  // [0..2] shader ticks, 100-MHz ticks, workgroups; [4..11] per-role stamps of staged tiles (rows_staged.inc)
-static __device__ unsigned long long g_clk[kClkWords];
+// One record of kClkWords counters per workgroup (blockIdx mod kClkRecords), ACCUMULATED with plain read-modify-writes by one lane of the
+// workgroup -- no atomics: thousands of workgroups adding to a handful of shared words serialise in the L2's atomic unit and slow the
+// very kernel that is being timed several-fold.  Words: [0] shader ticks the workgroup lived, [1] 100-MHz ticks, [2] workgroups;
+// staged tiles (rows_staged.inc): [4] producer ticks, [5] rows it found no free slot for at once, [6] source rows, [7] tiles;
+// [8] consumer ticks (sum of three), [9] ticks waiting for source rows, [10] of those before the first row, [11] rows.
+constexpr int kClkWords = 32, kClkRecords = 8192;  // (a record: words 0 .. 7 as listed, then [8 + 4 c ..] = the four consumer words of consumer c)
+static __device__ unsigned long long g_clk[kClkRecords * kClkWords];
+__device__ __forceinline__ void clk_add(int word, unsigned long long v) { g_clk[(blockIdx.x & (kClkRecords - 1)) * kClkWords + word] += v; }
 #endif
 // NSRC = 3 is warp_composite (bev/tool/compo.py:26-49) in one launch: a workgroup of 12 waves, four per source -- waves 0-3
 // warp the background, 4-7 the foreground, 8-11 its mask, each group exactly as a workgroup of the plain kernel would, every
@@ -89,7 +95,12 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // STAGED tiles (rows_staged.inc): one producer wave copies the tile's source rows into a ring of LDS slots with coalesced LDS-DMA
     // loads, three consumer waves read their taps from the ring.  The ring, two transposition rows per consumer and the four
     // hand-off words share the LDS of the deferred-store rows (a tile is processed one way or the other).
-    constexpr bool kStageable = NSRC == 1 && INTERP == kLinear && C == 3 && (sizeof(T) == 4 || RS4);
+    // MEASURED AND NOT ENABLED (round 4, profiles/r04_staged_tiles.txt): bit-exact on the whole GPU suite, and within +-3 % of the gather
+    // pipelines on float pixels (equal at 1080p with non-temporal ring fills, -3.4 % on the 4K shard) but 5 % SLOWER on 8-bit pixels,
+    // whose consumers carry 15 % more vector instructions (LDS addresses) on SIMDs that are already the limiter.  The fragment stays
+    // in the tree as the record of the experiment; `python tools/ablate.py stage=stage` builds a library with it switched on.
+    constexpr bool kStageEnabled = false;
+    constexpr bool kStageable = kStageEnabled && NSRC == 1 && INTERP == kLinear && C == 3 && (sizeof(T) == 4 || RS4);
     constexpr int kCons = kWaves - 1;                       // consumer waves of a staged tile
     constexpr int kRing = sizeof(T) == 1 ? 16 : 10;         // source rows the ring holds
     constexpr int kFlight = sizeof(T) == 1 ? 12 : 6;        // rows the producer keeps in flight (<= kRing - 2, rows_staged.inc)
@@ -99,7 +110,8 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     constexpr int kStageAux = 0;                            // cache policy of the ring fills (0: default, 2: nt)
     constexpr int kTrDwords = kWaves * NSRC * kRowsLds * TRW;
     constexpr int kLdsDwords = kStageable && (kStageFlagOff + 16) / 4 > kTrDwords ? (kStageFlagOff + 16) / 4 : kTrDwords;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kLdsDwords];
+    constexpr int kLdsWaves = (kLdsDwords + kRowsLds * TRW - 1) / (kRowsLds * TRW);  // (= kWaves * NSRC unless a staged build needs more: its layout is a byte view)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tr[kLdsWaves][kRowsLds][TRW];
     // (composite only) the warped tiles, one packed pixel per dword: [source][row of the tile][pixel]
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[NSRC > 1 ? NSRC * kCompositeRows * TW : 4];
     constexpr int NEED = LOADB / 4;  // dwords of a tap row the blend takes, starting AT the left tap
@@ -108,9 +120,9 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
         unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         __device__ ~ClockStamp() {
             if (threadIdx.x == 0) {
-                atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - t0);
-                atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
-                atomicAdd(&g_clk[2], 1ull);
+                clk_add(0, __builtin_amdgcn_s_memtime() - t0);
+                clk_add(1, __builtin_amdgcn_s_memrealtime() - r0);
+                clk_add(2, 1ull);
             }
         }
     } clock_stamp;
@@ -258,13 +270,17 @@ void launch_channels(const WarpArgs& a, int channels, dim3 grid, hipStream_t str
 
 #ifdef BEVWARP_CLOCK
 inline hipError_t read_clock_of_this_unit(unsigned long long* out16, int reset) {  // out16 += this translation unit's counters
-    unsigned long long v[kClkWords];
+    static unsigned long long v[kClkRecords * kClkWords];  // (2 MB: not on the stack; the diagnostic build is single-threaded)
     hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clk), sizeof(v));
     if (e != hipSuccess) return e;
-    for (int i = 0; i < kClkWords; i++) out16[i] += v[i];
+    for (int r = 0; r < kClkRecords; r++) {
+        for (int i = 0; i < 8; i++) out16[i] += v[r * kClkWords + i];
+        for (int i = 8; i < 20; i++) out16[8 + (i & 3)] += v[r * kClkWords + i];  // the three consumers' words, folded
+    }
     if (reset) {
-        unsigned long long z[kClkWords] = {};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z));
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_clk));
+        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(v));
     }
     return e;
 }

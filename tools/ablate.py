@@ -16,8 +16,10 @@ snippet):
     noedge    EDGE blocks cost what OUT blocks cost
     ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
-    nostage   no tile takes the LDS-staged producer / consumer form (rows_staged.inc): the gather pipelines only
-    stagent   the staged form's ring fills are non-temporal (aux = 2)
+    stage     interior row-affine tiles take the LDS-staged producer / consumer form (rows_staged.inc; off in the product)
+    stagent   (with stage) the staged form's ring fills are non-temporal (aux = 2)
+    pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
+    ntstore   the wide destination stores are non-temporal
     ring16 / ring4   the staged form's ring holds 16 / 4 source rows instead of 8
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
@@ -111,8 +113,13 @@ def patch(files, spec):
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || tile_in) {")
     elif spec == "ownblk":  # interior tiles: blocks whatever the slant
         rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
-    elif spec == "nostage":
-        rep("    constexpr bool kStageable = NSRC == 1 && INTERP == kLinear && C == 3 && (sizeof(T) == 4 || RS4);", "    constexpr bool kStageable = false;")
+    elif spec == "ntstore":  # the wide destination stores non-temporal (rounds 2-3 measured them slower on every format)
+        rep("    *p = v;\n}", "    __builtin_nontemporal_store(v, p);\n}")
+    elif spec in ("pwfix", "pws5"):  # the producer's wave index: always wave 3 / rotating with the dispatch order divided by the CUs of an XCD
+        rep("const int p_wave = (int)((blockIdx.x >> 3) & (uint32_t)(kWaves - 1));",
+            "const int p_wave = 3;" if spec == "pwfix" else "const int p_wave = (int)((blockIdx.x >> 8) & (uint32_t)(kWaves - 1));")
+    elif spec == "stage":
+        rep("    constexpr bool kStageEnabled = false;", "    constexpr bool kStageEnabled = true;")
     elif spec == "stagent":
         rep("    constexpr int kStageAux = 0; ", "    constexpr int kStageAux = 2; ")
     elif spec in ("ring16", "ring4"):
@@ -123,6 +130,11 @@ def patch(files, spec):
 
 
 def main():
+    # --clock: the diagnostic build (-DBEVWARP_CLOCK: per-workgroup and per-role stamps, tools/clock.py) of the patched sources; needs
+    # `make -C bev_amd/csrc variants/clock.so` first (its bevwarp_api / geom_kernels objects are linked in)
+    clock = "--clock" in sys.argv
+    if clock:
+        sys.argv.remove("--clock")
     base = {n: open(os.path.join(CSRC, n)).read() for n in KERNEL_FILES}
     os.makedirs(os.path.join(CSRC, "variants"), exist_ok=True)
     procs = []
@@ -137,7 +149,7 @@ def main():
             open(os.path.join(tmp, n), "w").write(t)
         for u in UNITS:  # the translation units themselves are never patched; they include the patched headers from tmp
             open(os.path.join(tmp, u + ".hip"), "w").write(open(os.path.join(CSRC, u + ".hip")).read())
-            cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + tmp, "-c", os.path.join(tmp, u + ".hip"), "-o", os.path.join(tmp, u + ".o")]
+            cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + (["-DBEVWARP_CLOCK"] if clock else []) + ["-I" + os.path.join(ROOT, "include"), "-I" + tmp, "-c", os.path.join(tmp, u + ".hip"), "-o", os.path.join(tmp, u + ".o")]
             procs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE)))
     for name, p in procs:
         err = p.communicate()[1].decode()
@@ -146,7 +158,8 @@ def main():
     for arg in sys.argv[1:]:
         name = arg.split("=", 1)[0]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", os.path.join(CSRC, "variants", name + ".so"),
-                               os.path.join(CSRC, "bevwarp_api.o"), os.path.join(CSRC, "geom_kernels.o")] + ["/tmp/ablate_%s/%s.o" % (name, u) for u in UNITS])
+                               os.path.join(CSRC, "variants/clock_bevwarp_api.o" if clock else "bevwarp_api.o"),
+                               os.path.join(CSRC, "variants/clock_geom_kernels.o" if clock else "geom_kernels.o")] + ["/tmp/ablate_%s/%s.o" % (name, u) for u in UNITS])
         print("built", name)
 
 

@@ -55,6 +55,6 @@ print("%s %s %s: %d workgroups, mean life %.0f shader ticks = %.2f us, clock hel
     args.dtype, args.interp, args.homography, out[2], out[0] / out[2], out[1] / out[2] / 100.0, 100.0 * out[0] / out[1]))
 if out[7]:  # staged tiles ran (rows_staged.inc): per-role stamps, shader ticks
     P, C = out[7], out[7] * 3
-    print("staged tiles %d: producer life %.0f ticks (waiting for a free slot %.0f, for rows to land %.0f); consumer life %.0f ticks, %.1f rows each "
-          "(waiting for source rows %.0f, of which before its first row %.0f)" % (
-              P, out[4] / P, out[5] / P, out[6] / P, out[8] / C, out[11] / C, out[9] / C, out[10] / C))
+    print("staged tiles %d: producer life %.0f ticks, %.1f source rows of which %.2f found no free slot at once; consumer life %.0f ticks, %.1f rows each, "
+          "waiting for source rows %.0f ticks (%.0f %% of its life), of which before its first row %.0f (%.0f %%)" % (
+              P, out[4] / P, out[6] / P, out[5] / P, out[8] / C, out[11] / C, out[9] / C, 100.0 * out[9] / out[8], out[10] / C, 100.0 * out[10] / out[8]))
