@@ -16,6 +16,7 @@ snippet):
     noedge    EDGE blocks cost what OUT blocks cost
     ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
+    nostagger / revrows / lpt   dispatch-order experiments: no XCD stagger / a frame's tile rows bottom-up / an XCD walks all its frames tile row by tile row
     stage     interior row-affine tiles take the LDS-staged producer / consumer form (rows_staged.inc; off in the product)
     stagent   (with stage) the staged form's ring fills are non-temporal (aux = 2)
     pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
@@ -118,6 +119,18 @@ def patch(files, spec):
     elif spec in ("pwfix", "pws5"):  # the producer's wave index: always wave 3 / rotating with the dispatch order divided by the CUs of an XCD
         rep("const int p_wave = (int)((blockIdx.x >> 3) & (uint32_t)(kWaves - 1));",
             "const int p_wave = 3;" if spec == "pwfix" else "const int p_wave = (int)((blockIdx.x >> 8) & (uint32_t)(kWaves - 1));")
+    elif spec == "nostagger":  # every XCD starts at the first item of its run
+        rep("    uint32_t in_run = seq + (blockIdx.x & 7u) * (uint32_t)a.stagger;", "    uint32_t in_run = seq;")
+    elif spec == "revrows":  # a frame's tile rows from the bottom up
+        rep("    const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;",
+            "    const uint32_t ty_ = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty_ * (uint32_t)a.tiles_x, ty = (uint32_t)(a.tiles_per_frame / a.tiles_x) - 1u - ty_;")
+    elif spec == "lpt":  # an XCD walks its frames tile row by tile row (row r of all its frames, then row r + 1 ...): the run ends with every frame's last rows
+        rep("    const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);\n    const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;\n",
+            "    uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);\n    uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;\n"
+            "    if ((uint32_t)a.chunk % (uint32_t)a.tiles_per_frame == 0u) {\n"
+            "        const uint32_t fpx = (uint32_t)a.chunk / (uint32_t)a.tiles_per_frame, per_row = fpx * (uint32_t)a.tiles_x;\n"
+            "        const uint32_t r = in_run / per_row, rem = in_run - r * per_row, f = rem / (uint32_t)a.tiles_x;\n"
+            "        frame_idx = (blockIdx.x & 7u) * fpx + f;\n        t = r * (uint32_t)a.tiles_x + (rem - f * (uint32_t)a.tiles_x);\n    }\n")
     elif spec == "stage":
         rep("    constexpr bool kStageEnabled = false;", "    constexpr bool kStageEnabled = true;")
     elif spec == "stagent":
