@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("BEVWARP_LIB") or os.path.join(_CSRC, "libbevwarp.so")
 
 U8, F32, F64 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/bevwarp.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -30,6 +30,8 @@ SYMBOLS = {
     "bevwarp_composite": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     "bevwarp_warp_composite": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int64,
                                           _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
+    "bevwarp_resize": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64,
+                                  _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
     "bevwarp_footprint": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int,
                                      _c.c_int, _c.c_void_p]),
     "bevwarp_project_points": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),

@@ -304,6 +304,22 @@ int bevwarp_warp_composite(const void* bg, int bg_h, int bg_w, int64_t bg_row_st
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
 
+int bevwarp_resize(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int64_t src_frame_stride,
+                   int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, int dtype, int interp, void* stream) {
+    if (!src || !dst || batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
+    if (dtype != BEVWARP_U8 || interp != BEVWARP_LINEAR || channels < 1 || channels > 4) return BEVWARP_ERR_UNSUPPORTED;
+    if (src_row_stride < (int64_t)src_w * channels || dst_row_stride < (int64_t)dst_w * channels) return BEVWARP_ERR_BAD_ARG;
+    if (batch > 1 && (src_frame_stride < src_h * src_row_stride || dst_frame_stride < dst_h * dst_row_stride)) return BEVWARP_ERR_BAD_ARG;
+    if (src_w > (1 << 24) || src_h > (1 << 24) || dst_w > (1 << 24) || dst_h > 65535 || batch > 65535) return BEVWARP_ERR_TOO_LARGE;
+    if (batch == 0) return BEVWARP_OK;
+    if (regions_overlap((uintptr_t)src, (uint64_t)src_w * channels, src_h, src_row_stride, src_frame_stride, (uintptr_t)dst, (uint64_t)dst_w * channels, dst_h,
+                        dst_row_stride, dst_frame_stride, batch))
+        return BEVWARP_ERR_OVERLAP;
+    const hipError_t e = bevwarp::launch_resize_linear_u8((const uint8_t*)src, (uint8_t*)dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride,
+                                                          src_row_stride, dst_frame_stride, dst_row_stride, (hipStream_t)stream);
+    return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
+}
+
 int bevwarp_footprint(unsigned char* touched, int batch, int src_h, int src_w, int dst_h, int dst_w, const double* M_inv, int m_count,
                       int interp, void* stream) {
     if (!touched || !M_inv || batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;

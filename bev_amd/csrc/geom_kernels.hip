@@ -8,6 +8,7 @@
 // one lane per pair: circumscribed-circle rejection first, convex clipping for the pairs that may touch.
 // Latency/ALU bound (output ~1 MB).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "warp_kernels.h"
@@ -171,21 +172,24 @@ __device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B
     return fabs(0.5 * a);
 }
 
-// IoU of box A (cx, cy, w, h, yaw in float64) with the box at pb: circumscribed-circle rejection, then the clip.
-// Boxes whose circumscribed circles are apart cannot intersect: the clip would return exactly 0 for them.  In a tracker
-// step almost every pair ends there, before any sin / cos or clipping (the 1e-4 margin keeps near-touching pairs on the
-// exact path; NaNs fall through to it as well).
-template <typename T>
-__device__ __forceinline__ double pair_iou(const double (&A)[5], const T* __restrict__ pb, double* __restrict__ lds, int tid) {
-    const double bx = (double)pb[0], by = (double)pb[1], bw = (double)pb[2], bh = (double)pb[3];
-    const double dx = A[0] - bx, dy = A[1] - by;
-    const double ra2 = A[2] * A[2] + A[3] * A[3], rb2 = bw * bw + bh * bh;
-    const double rs = 0.5 * (sqrt(ra2) + sqrt(rb2));
-    if (dx * dx + dy * dy > rs * rs * 1.0001 && fabs(A[2] * A[3]) + fabs(bw * bh) > 0) return 0.0;
+// IoU of box A with box B, both [cx, cy, w, h, yaw] in float64.  First a rejection test that needs no square root and no sin / cos:
+// the circumscribed circles have diameters sqrt(w^2 + h^2), and ((da + db) / 2)^2 <= (da^2 + db^2) / 2, so centres further apart than
+// that bound belong to boxes that cannot intersect -- the clip would return exactly 0 for them, which is what is returned.  In a tracker
+// step almost every pair ends there (round 3 spent two float64 square roots on every pair before it could say so; the 1e-4 margin keeps
+// near-touching pairs on the exact path; NaNs fall through to it as well).  Only pairs that may touch build their corners (sin / cos)
+// and clip.  `A` is produced by `box_a()` only when needed: the tracker step's detection yaw costs a sincos and an atan2.
+template <typename BoxA>
+__device__ __forceinline__ double pair_iou(double acx, double acy, double aw, double ah, BoxA&& box_a, const double (&B)[5], double* __restrict__ lds, int tid) {
+    const double dx = acx - B[0], dy = acy - B[1];
+    const double da2 = aw * aw + ah * ah, db2 = B[2] * B[2] + B[3] * B[3];
+    const double area = fabs(aw * ah) + fabs(B[2] * B[3]);
+    if (dx * dx + dy * dy > 0.5 * (da2 + db2) * 1.0001 && area > 0) return 0.0;
+    double A[5];
+    box_a(A);
     const Quad QA = corners_of(A[0], A[1], A[2], A[3], A[4]);
-    const Quad QB = corners_of(bx, by, bw, bh, (double)pb[4]);
+    const Quad QB = corners_of(B[0], B[1], B[2], B[3], B[4]);
     const double inter = intersection_area(QA, QB, lds, tid);
-    const double uni = fabs(A[2] * A[3]) + fabs(bw * bh) - inter;
+    const double uni = area - inter;
     return uni > 0 ? inter / uni : 0.0;
 }
 
@@ -197,8 +201,13 @@ __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restri
     const int i = blockIdx.y;
     if (j >= nb) return;
     const T* pa = a + (int64_t)i * sa;
+    const T* pb = b + (int64_t)j * sb;
     const double A[5] = {(double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]};
-    out[(int64_t)i * nb + j] = (T)pair_iou<T>(A, b + (int64_t)j * sb, s_poly, (int)threadIdx.x);
+    const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
+    out[(int64_t)i * nb + j] = (T)pair_iou(A[0], A[1], A[2], A[3], [&](double (&o)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) o[k] = A[k];
+    }, B, s_poly, (int)threadIdx.x);
 }
 
 // ---- rotated boxes through a similarity H (reference bev/rbox.py:173-219) ------------------------------------------
@@ -235,40 +244,47 @@ __global__ __launch_bounds__(256) void rbox_transform_kernel(const T* __restrict
 }
 
 // ---- one tracker step in one launch (reference bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 with the association
-// front-end of bev/tracker/rbox_tracker.py:383-405): block (jb, i) moves detection i from the BEV raster to the world
-// (thread 0, shared through LDS), scores it against 256 predicted tracker boxes, and writes the IoU row segment and the
-// `iou > threshold` gate; block (0, i) also writes the world box and its image-plane centre (rbox_world_img, rbox.py:221-226).
+// front-end of bev/tracker/rbox_tracker.py:383-405): block (jb, i) scores detection i against 64 predicted tracker boxes and writes the
+// IoU row segment and the `iou > threshold` gate; block (0, i) also writes the world box and its image-plane centre (rbox_world_img,
+// rbox.py:221-226).  What a pair needs first is only the detection's world CENTRE and SIZE (two divisions): the yaw -- a sincos and an
+// atan2, the long dependent chain round 3 ran in thread 0 of every block before anybody could start -- is needed by the few pairs that
+// survive the rejection test and by block (0, i)'s output, and is computed there (after the pairs have been scored and stored).
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __restrict__ dets, int n, int sd, const T* __restrict__ trks, int m, int st,
                                                                    const SimH Hwb, const H9 Him, int has_img, double thr, T* __restrict__ dets_world,
                                                                    T* __restrict__ iou, uint8_t* __restrict__ cand, T* __restrict__ dets_img) {
     __shared__ double s_poly[2 * 2 * 8 * kIouThreads];
-    __shared__ double s_box[5];
     const int i = blockIdx.y, tid = (int)threadIdx.x;
     const int j = blockIdx.x * blockDim.x + tid;
-    if (tid == 0) {
+    const T* pd = dets + (int64_t)i * sd;
+    // centre and size of the detection in the world, as box_through computes them (every lane: the same scalars, no LDS round trip);
+    // rounded to the storage type like the dets_world output -- the box the tracker would see
+    const double x = (double)pd[0], y = (double)pd[1];
+    const double X = Hwb.h[0] * x + Hwb.h[1] * y + Hwb.h[2], Y = Hwb.h[3] * x + Hwb.h[4] * y + Hwb.h[5], W = Hwb.h[6] * x + Hwb.h[7] * y + Hwb.h[8];
+    const double acx = (double)(T)(X / W), acy = (double)(T)(Y / W), aw = (double)(T)((double)pd[2] * Hwb.scale), ah = (double)(T)((double)pd[3] * Hwb.scale);
+    if (j < m) {
+        const T* pb = trks + (int64_t)j * st;
+        const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
+        const double v = pair_iou(acx, acy, aw, ah, [&](double (&o)[5]) {
+            box_through<T>(pd, Hwb, 1, o);
+#pragma unroll
+            for (int k = 0; k < 5; k++) o[k] = (double)(T)o[k];
+        }, B, s_poly, tid);
+        iou[(int64_t)i * m + j] = (T)v;
+        cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
         double o[5];
-        box_through<T>(dets + (int64_t)i * sd, Hwb, 1, o);
+        box_through<T>(pd, Hwb, 1, o);
 #pragma unroll
-        for (int k = 0; k < 5; k++) s_box[k] = o[k];
-        if (blockIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) dets_world[(int64_t)i * 5 + k] = (T)o[k];
-            if (has_img) {
-                const double X = Him.h[0] * o[0] + Him.h[1] * o[1] + Him.h[2], Y = Him.h[3] * o[0] + Him.h[4] * o[1] + Him.h[5];
-                const double W = Him.h[6] * o[0] + Him.h[7] * o[1] + Him.h[8];
-                dets_img[(int64_t)i * 2] = (T)(X / W);
-                dets_img[(int64_t)i * 2 + 1] = (T)(Y / W);
-            }
+        for (int k = 0; k < 5; k++) dets_world[(int64_t)i * 5 + k] = (T)o[k];
+        if (has_img) {
+            const double Xi = Him.h[0] * o[0] + Him.h[1] * o[1] + Him.h[2], Yi = Him.h[3] * o[0] + Him.h[4] * o[1] + Him.h[5];
+            const double Wi = Him.h[6] * o[0] + Him.h[7] * o[1] + Him.h[8];
+            dets_img[(int64_t)i * 2] = (T)(Xi / Wi);
+            dets_img[(int64_t)i * 2 + 1] = (T)(Yi / Wi);
         }
     }
-    __syncthreads();
-    if (j >= m) return;
-    // (the box the tracker would see: rounded to the storage type like the dets_world output)
-    const double A[5] = {(double)(T)s_box[0], (double)(T)s_box[1], (double)(T)s_box[2], (double)(T)s_box[3], (double)(T)s_box[4]};
-    const double v = pair_iou<T>(A, trks + (int64_t)j * st, s_poly, tid);
-    iou[(int64_t)i * m + j] = (T)v;
-    cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);
 }
 
 // ---- alpha composite (reference bev/tool/compo.py:16-23) ------------------------------------------------
@@ -297,6 +313,62 @@ __global__ __launch_bounds__(256) void composite_kernel(const uint8_t* bg, const
         return;
     }
     for (int64_t i = i0; i < n && i < i0 + 16; i++) out[i] = (uint8_t)composite_byte(bg[i], fg[i], mask[i]);
+}
+
+// ---- cv2.resize(img, (w, h)), INTER_LINEAR, 8-bit: the resize the reference's "small" branch applies before it warps
+// (vis_homo.py:90).  OpenCV's classic bilinear path (resize.cpp, restated from memory -- parity unpinned, oracle/resize_oracle.c):
+// sampling position (d + 0.5) * scale - 0.5 evaluated in float64 and rounded to float32, fraction in float32, 11-bit coefficients
+// (saturate_cast<short>((1 - f) * 2048), (f * 2048)), the horizontal sums as integers, the vertical pass
+// ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2; columns whose right tap would lie beyond the last source column read ONE
+// tap with weight 2048, rows are clipped to the image and keep their coefficients.  One lane per destination pixel.
+__device__ __forceinline__ void resize_axis(int d, double scale, int src_n, bool clamp, int& s, int& c0, int& c1, bool& one_tap) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    one_tap = false;
+    if (clamp) {
+        if (s < 0) s = 0, f = 0.f;
+        if (s + 1 >= src_n) {
+            one_tap = true;  // (the first clamped column and every one after it: sx is monotone in dx)
+            if (s >= src_n - 1) s = src_n - 1, f = 0.f;
+        }
+    }
+    auto sat = [](float v) {
+        const float r = rintf(v);
+        return (int)fminf(fmaxf(r, -32768.f), 32767.f);
+    };
+    c0 = sat((1.f - f) * 2048.f);
+    c1 = sat(f * 2048.f);
+}
+template <int C>
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int src_h, int src_w, int dst_h, int dst_w,
+                                                               int64_t src_fs, int64_t src_rs, int64_t dst_fs, int64_t dst_rs, double scale_x, double scale_y,
+                                                               int box2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dst_w) return;
+    const uint8_t* frame = src + (int64_t)blockIdx.z * src_fs;
+    uint8_t* d = dst + (int64_t)blockIdx.z * dst_fs + (int64_t)y * dst_rs + (int64_t)x * C;
+    if (box2) {  // scale exactly 2 x 2: INTER_LINEAR is INTER_AREA's box mean there
+        const uint8_t* r0 = frame + (int64_t)(2 * y) * src_rs + (int64_t)(2 * x) * C;
+        const uint8_t* r1 = r0 + src_rs;
+#pragma unroll
+        for (int k = 0; k < C; k++) d[k] = (uint8_t)(((int)r0[k] + (int)r0[C + k] + (int)r1[k] + (int)r1[C + k] + 2) >> 2);
+        return;
+    }
+    int sx, a0, a1, sy, b0, b1;
+    bool one, unused;
+    resize_axis(x, scale_x, src_w, true, sx, a0, a1, one);
+    resize_axis(y, scale_y, src_h, false, sy, b0, b1, unused);
+    const int y0 = min(max(sy, 0), src_h - 1), y1 = min(max(sy + 1, 0), src_h - 1);
+    const uint8_t* p0 = frame + (int64_t)y0 * src_rs + (int64_t)sx * C;
+    const uint8_t* p1 = frame + (int64_t)y1 * src_rs + (int64_t)sx * C;
+    const int right = one ? 0 : C;  // (never read beyond the row: a one-tap column takes its own pixel twice, the second with weight 0)
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const int h0 = one ? (int)p0[k] * 2048 : (int)p0[k] * a0 + (int)p0[right + k] * a1;
+        const int h1 = one ? (int)p1[k] * 2048 : (int)p1[k] * a0 + (int)p1[right + k] * a1;
+        d[k] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
 }
 
 }  // namespace
@@ -342,6 +414,29 @@ hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, i
         hipLaunchKernelGGL(rbox_iou_kernel<double>, grid, block, 0, stream, (const double*)a, na, a_stride, (const double*)b, nb, b_stride, (double*)out);
     else
         hipLaunchKernelGGL(rbox_iou_kernel<float>, grid, block, 0, stream, (const float*)a, na, a_stride, (const float*)b, nb, b_stride, (float*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int64_t src_fs,
+                                   int64_t src_rs, int64_t dst_fs, int64_t dst_rs, hipStream_t stream) {
+    (void)hipGetLastError();
+    // cv::resize: scale = 1 / ((double)dst / src) -- two roundings, not src / dst
+    const double scale_x = 1.0 / ((double)dst_w / src_w), scale_y = 1.0 / ((double)dst_h / src_h);
+    const int box2 = fabs(scale_x - 2.0) < 2.220446049250313e-16 && fabs(scale_y - 2.0) < 2.220446049250313e-16;
+    const dim3 block(256), grid((dst_w + 255) / 256, dst_h, batch);
+#define BEVWARP_RESIZE_CASE(C)                                                                                                                         \
+    case C:                                                                                                                                            \
+        hipLaunchKernelGGL(resize_linear_u8_kernel<C>, grid, block, 0, stream, src, dst, src_h, src_w, dst_h, dst_w, src_fs, src_rs, dst_fs, dst_rs, \
+                           scale_x, scale_y, box2);                                                                                                    \
+        break;
+    switch (channels) {
+        BEVWARP_RESIZE_CASE(1)
+        BEVWARP_RESIZE_CASE(2)
+        BEVWARP_RESIZE_CASE(3)
+        default:
+            BEVWARP_RESIZE_CASE(4)
+    }
+#undef BEVWARP_RESIZE_CASE
     return hipGetLastError();
 }
 

@@ -52,6 +52,8 @@ hipError_t launch_composite(const uint8_t* bg, const uint8_t* fg, const uint8_t*
 hipError_t launch_rbox_iou(const void* a, int na, int a_stride, const void* b, int nb, int b_stride, void* out, int dtype,
                            hipStream_t stream);
 
+hipError_t launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int64_t src_fs,
+                                   int64_t src_rs, int64_t dst_fs, int64_t dst_rs, hipStream_t stream);
 hipError_t launch_rbox_transform(const void* in, int n, int stride, const double* H, double scale, int src_is_bev, void* out, int dtype, hipStream_t stream);
 hipError_t launch_tracker_step(const void* dets, int n, int det_stride, const void* trks, int m, int trk_stride, const double* H_world_bev, double scale,
                                const double* H_img_world, double iou_threshold, void* dets_world, void* iou, unsigned char* cand, void* dets_img,

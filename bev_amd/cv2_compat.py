@@ -10,9 +10,12 @@ and leave /root/reference/vis_homo.py:89-91, bev/homo.py:36 and bev/tool/compo.p
     cv2.perspectiveTransform(pts (N,1,2), H) -> (N,1,2)                          (OpenCV's name for pts_world_bev, bev/rbox.py:136-151)
     cv2.invert(M) -> (retval, M_inv)                                             the 3x3 step inside warpPerspective
 
-`cv2.resize` (vis_homo.py:90) is deliberately NOT here: a resize routed through the warp kernel (1/32-px positions, constant
-border) is not cv2.resize (11-bit coefficients, replicated edge) and a shim that returns different pixels under cv2's name is
-a trap.  Under `python -m bev_amd.run` the real cv2 keeps its resize; on the fast path the "small" branch needs none
+    cv2.resize(img, (w, h)[, dst, fx, fy, interpolation])                        vis_homo.py:90 (uint8, INTER_LINEAR only)
+
+`cv2.resize` here is OpenCV's own bilinear algorithm (sampling at (d + 0.5) * scale - 0.5, 11-bit coefficients, replicated edge, the
+2 x 2 box-mean rule) as its own device kernel -- round 3 had none, because a resize routed through the WARP kernel (1/32-px
+positions, constant border) returns different pixels and must not carry cv2's name.  Restated from memory like the warp: parity
+unpinned.  Under `python -m bev_amd.run` a real cv2 keeps its own resize; on the fast path the "small" branch needs none
 (bev_amd.warp.warp_perspective_resized folds the resize into the homography).
 
 Pixel work runs on the GPU through libbevwarp.so (no CPU fallback); numpy images go up and come back per call, which is
@@ -22,6 +25,7 @@ still needs from a real cv2.
 """
 import numpy as np
 
+from . import resize as _resize
 from . import warp as _warp
 from .homo import homo_from_pts as _homo_from_pts
 from .rbox import pts_world_bev as _pts_world_bev
@@ -42,6 +46,12 @@ def warpPerspective(src, M, dsize, dst=None, flags=INTER_LINEAR, borderMode=BORD
     BORDER_CONSTANT with cv::Scalar border semantics.  Bit-exact with the classic fixed-point algorithm
     (oracle/warp_oracle.c states which OpenCV code path that is)."""
     return _warp.warpPerspective(src, M, dsize, dst=dst, flags=flags, borderMode=borderMode, borderValue=borderValue)
+
+
+def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=INTER_LINEAR):
+    """uint8 images of 1-4 channels, INTER_LINEAR (cv2.resize's default; the reference passes none).  Bit-exact with
+    oracle/resize_oracle.c (classic OpenCV 3.x-4.x bilinear path, restated from memory: parity unpinned)."""
+    return _resize.cv2_resize(src, dsize, dst=dst, fx=fx, fy=fy, interpolation=interpolation)
 
 
 def findHomography(srcPoints, dstPoints, method=0, ransacReprojThreshold=3.0, mask=None, maxIters=2000, confidence=0.995):

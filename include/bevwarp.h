@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define BEVWARP_ABI_VERSION 5
+#define BEVWARP_ABI_VERSION 6
 
 typedef enum bevwarp_status {
     BEVWARP_OK = 0,
@@ -138,6 +138,17 @@ int bevwarp_warp_composite(const void *bg, int bg_h, int bg_w, int64_t bg_row_st
                            int fg_h, int fg_w, int64_t fg_row_stride, int64_t mask_row_stride, void *dst, int dst_h,
                            int dst_w, int64_t dst_row_stride, int channels, const double *M_inv_bg,
                            const double *M_inv_cam, int fg_gray, void *stream);
+
+/*
+ * dst[b] = cv2.resize(src[b], (dst_w, dst_h)) with the default INTER_LINEAR, uint8, `channels` (1..4) interleaved -- the resize of the
+ * reference's "small" branch (img_small = cv2.resize(img, (new_u, new_v)), vis_homo.py:90) in front of its warp (:91).  OpenCV's classic
+ * bilinear path: sampling at (d + 0.5) * scale - 0.5, 11-bit coefficients, replicated edge, an exact 2 x 2 decimation = the box mean
+ * (restated from memory of resize.cpp; parity unpinned -- oracle/resize_oracle.c).  dtype must be BEVWARP_U8, interp BEVWARP_LINEAR.
+ * Device pointers, strides in bytes; src and dst must not overlap (BEVWARP_ERR_OVERLAP).
+ */
+int bevwarp_resize(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                   int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, int dtype,
+                   int interp, void *stream);
 
 /*
  * Marks every in-bounds source pixel that any tap of any destination pixel of the same warp would

@@ -4,6 +4,7 @@ What each entry restates (reference file:line):
   warp_perspective   cv2.warpPerspective as called at /root/reference/vis_homo.py:89,91 and
                      /root/reference/bev/tool/compo.py:38,46,47  (parity unpinned -- OpenCV absent)
   project_points     pts_world_bev, /root/reference/bev/rbox.py:136-151  (pinned by tests/golden)
+  resize_linear_u8   cv2.resize(img, (w, h)) (INTER_LINEAR) as called at /root/reference/vis_homo.py:90  (parity unpinned)
   rbox_iou           d3d.box.box2d_iou(.., method="rbox") as called at
                      /root/reference/bev/tracker/rbox_tracker.py:87-92   (parity unpinned -- d3d absent)
 """
@@ -24,8 +25,8 @@ _lib = None
 
 def build(force=False):
     """gcc the oracle (a few hundred ms).  Called by __graft_entry__.build() and lazily by load()."""
-    src = os.path.join(_HERE, "warp_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("warp_oracle.c", "resize_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -33,8 +34,7 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()  # (a no-op unless a source is newer than the library)
         lib = ctypes.CDLL(_SO)
         c = ctypes
         lib.oracle_invert3x3.argtypes = [c.c_void_p, c.c_void_p]
@@ -54,6 +54,8 @@ def load():
         lib.oracle_project_points_f32.restype = c.c_int
         lib.oracle_rbox_iou.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_int, c.c_void_p]
         lib.oracle_rbox_iou.restype = c.c_int
+        lib.oracle_resize_linear_u8.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int64, c.c_void_p, c.c_int, c.c_int, c.c_int64, c.c_int]
+        lib.oracle_resize_linear_u8.restype = c.c_int
         lib.oracle_rbox_iou_pair.argtypes = [c.c_void_p, c.c_void_p]
         lib.oracle_rbox_iou_pair.restype = c.c_double
         _lib = lib
@@ -139,4 +141,17 @@ def rbox_iou(a, b):
     b = np.ascontiguousarray(b, dtype=np.float64)
     out = np.empty((a.shape[0], b.shape[0]), np.float64)
     load().oracle_rbox_iou(_p(a), a.shape[0], a.shape[1], _p(b), b.shape[0], b.shape[1], _p(out))
+    return out
+
+
+def resize_linear_u8(img, dsize):
+    """cv2.resize(img, dsize) for uint8 (H, W) / (H, W, C) images, default INTER_LINEAR (oracle/resize_oracle.c)."""
+    img = np.ascontiguousarray(img)
+    assert img.dtype == np.uint8 and img.ndim in (2, 3)
+    c = 1 if img.ndim == 2 else img.shape[2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = np.empty((dh, dw) + (() if img.ndim == 2 else (c,)), np.uint8)
+    st = load().oracle_resize_linear_u8(_p(img), img.shape[0], img.shape[1], img.strides[0], _p(out), dh, dw, out.strides[0], c)
+    if st != 0:
+        raise ValueError("oracle_resize_linear_u8 failed: %d" % st)
     return out

@@ -72,9 +72,9 @@ def test_vis_homo_sequence_through_the_reference_names(golden, tmp_path):
     new_u, new_v = 852, 480
     calib_small = calib.scale(align_corners=False, new_u=new_u, new_v=new_v)
     H_bev_img_small = np.linalg.inv(H_world_bev).dot(calib_small.gen_H_world_img())
-    assert not hasattr(cv2, "resize")  # exact or absent: the shim does not pass a warp-kernel resize off as cv2.resize
-    ys, xs = (np.arange(new_v) * 1080) // new_v, (np.arange(new_u) * 1920) // new_u
-    img_small = np.ascontiguousarray(img[ys][:, xs])  # any resized frame will do for the second warp's parity
+    img_small = cv2.resize(img, (new_u, new_v))  # vis_homo.py:90, as written: OpenCV's own bilinear algorithm as a device kernel
+    assert img_small.shape == (new_v, new_u, 3) and img_small.dtype == np.uint8
+    np.testing.assert_array_equal(img_small, co.resize_linear_u8(img, (new_u, new_v)))
     bev_small = cv2.warpPerspective(img_small, H_bev_img_small, (bspec.u_size, bspec.v_size))
     np.testing.assert_array_equal(bev_small, co.warp_perspective(img_small, H_bev_img_small, (bspec.u_size, bspec.v_size), 1))
     # ... and fused: the full-resolution frame sampled once through H_small @ S (no intermediate image)
@@ -82,6 +82,10 @@ def test_vis_homo_sequence_through_the_reference_names(golden, tmp_path):
     S = warp.resize_matrix((1920, 1080), (new_u, new_v))
     np.testing.assert_array_equal(fused, co.warp_perspective(img, H_bev_img_small @ S, (bspec.u_size, bspec.v_size), 1))
     assert fused.shape == bev_small.shape and fused.dtype == np.uint8
+    # the two forms of the small branch see the same scene: the two-step one low-passes through the resize, so they differ by grey levels,
+    # not by geometry (mean |difference| on a noise image stays far below the noise's own contrast)
+    both = (bev_small > 0).all(axis=2) & (fused > 0).all(axis=2)
+    assert both.mean() > 0.3 and np.abs(bev_small[both].astype(np.int32) - fused[both].astype(np.int32)).mean() < 64
 
 
 def _real_cv2():
@@ -89,6 +93,18 @@ def _real_cv2():
     if not hasattr(cv2, "warpPerspective") or getattr(cv2, "__version__", "").startswith("bev_amd"):
         pytest.skip("`cv2` resolves to a stand-in, not to OpenCV")
     return cv2
+
+
+def test_opencv_cross_check_of_the_resize_oracle_when_present():
+    """The only thing that can pin oracle/resize_oracle.c is a real cv2: when one is importable, cv2.resize (INTER_LINEAR, uint8) must
+    agree within 1 LSB (exactly on the classic fixed-point path the oracle restates)."""
+    cv2 = _real_cv2()
+    from oracle import cpu_oracle as co
+    from tests import workloads as wl
+    for shape, dsize in (((1080, 1920, 3), (852, 480)), ((64, 48, 1), (31, 17)), ((40, 64, 3), (32, 20)), ((33, 65, 3), (130, 99))):
+        img = wl.frame(4, shape[0], shape[1], np.uint8, shape[2])
+        got = cv2.resize(img, dsize).reshape(dsize[1], dsize[0], shape[2])
+        assert np.abs(got.astype(np.int32) - co.resize_linear_u8(img, dsize).astype(np.int32)).max() <= 1
 
 
 def test_opencv_cross_check_of_the_oracle_when_present():

@@ -365,3 +365,57 @@ def test_validated_launch_cache_hits_and_misses(W):
     W.warp_perspective(src, None, (dw, dh), out=torch.empty_like(out), M_inv_device=minv)
     assert len(W._plans) <= 4
     W._plans.clear()
+
+
+@pytest.mark.parametrize("shape,dsize", [((1080, 1920, 3), (852, 480)), ((720, 1280, 3), (640, 360)), ((37, 53, 1), (100, 64)), ((64, 48, 4), (31, 17)),
+                                         ((5, 7, 3), (1, 1)), ((1, 1, 3), (9, 4)), ((480, 852, 2), (1920, 1080)), ((33, 65), (17, 9)), ((40, 64, 3), (32, 20))])
+def test_resize_matches_the_oracle(shape, dsize):
+    """bevwarp_resize == oracle/resize_oracle.c (cv2.resize INTER_LINEAR uint8 as called at vis_homo.py:90; parity unpinned) bit for bit:
+    the reference's own 1080p -> 852 x 480, magnification, 1-4 channels, degenerate sizes, the exact 2 x 2 box-mean case."""
+    from bev_amd.resize import cv2_resize, resize
+    c = shape[2] if len(shape) == 3 else 1
+    img = wl.frame(21, shape[0], shape[1], np.uint8, c)
+    if len(shape) == 2:
+        img = img[:, :, 0]
+    exp = co.resize_linear_u8(img, dsize)
+    got = resize(torch.from_numpy(img).cuda(), dsize)
+    torch.cuda.synchronize()
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    np.testing.assert_array_equal(cv2_resize(img, dsize), exp)  # numpy in, numpy out: cv2's call shape
+
+
+def test_resize_batches_views_and_errors():
+    from bev_amd.resize import cv2_resize, resize
+    frames = np.stack([wl.frame(30 + i, 90, 160, np.uint8) for i in range(5)])
+    t = torch.from_numpy(frames).cuda()
+    got = resize(t, (71, 40)).cpu().numpy()
+    for i in range(5):
+        np.testing.assert_array_equal(got[i], co.resize_linear_u8(frames[i], (71, 40)))
+    big = torch.from_numpy(wl.frame(7, 90, 200, np.uint8)).cuda()
+    view = big[:, 8:168]  # row-padded view, no copy
+    out = torch.full((40, 71, 3), 77, dtype=torch.uint8, device="cuda")
+    assert resize(view, (71, 40), out=out) is out
+    np.testing.assert_array_equal(out.cpu().numpy(), co.resize_linear_u8(np.ascontiguousarray(view.cpu().numpy()), (71, 40)))
+    np.testing.assert_array_equal(cv2_resize(frames[0], None, fx=0.5, fy=0.5), co.resize_linear_u8(frames[0], (80, 45)))  # exact 2 x 2: the box mean
+    with pytest.raises(ValueError):
+        resize(t.float(), (8, 8))
+    with pytest.raises(ValueError):
+        resize(t, (8, 8), interpolation=0)
+    with pytest.raises(ValueError):
+        resize(t, (0, 8))
+    with pytest.raises(ValueError, match="overlap"):
+        resize(big[:, :100], (100, 90), out=big[:, 50:150])
+
+
+def test_two_step_small_branch_pixel_for_pixel():
+    """vis_homo.py:73-78,90-91 as the reference runs it: resize to 852 x 480, then warp with the scaled calibration's homography; both
+    steps on the device, compared with the oracle's two steps."""
+    from bev_amd.resize import resize
+    from bev_amd import warp
+    img = wl.frame(0, 1080, 1920, np.uint8)
+    M_small = wl.synth_brno_H(852, 480, 320, 640)
+    t = torch.from_numpy(img).cuda()
+    got = warp.warp_perspective(resize(t, (852, 480)), M_small, (320, 640)).cpu().numpy()
+    exp = co.warp_perspective(co.resize_linear_u8(img, (852, 480)), M_small, (320, 640), 1)
+    np.testing.assert_array_equal(got, exp)
