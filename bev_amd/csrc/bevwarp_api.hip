@@ -374,7 +374,7 @@ int bevwarp_tracker_step(const void* dets_bev, int n, int det_stride, const void
     if (n > 0 && m > 0 && (!trks_world || !iou || !candidates)) return BEVWARP_ERR_BAD_ARG;
     if (H_img_world && n > 0 && !dets_img) return BEVWARP_ERR_BAD_ARG;
     if (dtype != BEVWARP_F32 && dtype != BEVWARP_F64) return BEVWARP_ERR_UNSUPPORTED;
-    if (n > 65535) return BEVWARP_ERR_TOO_LARGE;
+    if (n > 64000) return BEVWARP_ERR_TOO_LARGE;  // (grid rows: n scoring + n / 64 output workgroups <= 65535)
     if (!(iou_threshold == iou_threshold)) return BEVWARP_ERR_NOT_FINITE;
     double Hn[9], scale;
     const int st = normalise_similarity(H_world_bev, Hn, &scale);

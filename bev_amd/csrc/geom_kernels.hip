@@ -107,10 +107,11 @@ struct Quad {
     double x[4], y[4];
 };
 
-__device__ __forceinline__ Quad corners_of(double cx, double cy, double w, double h, double yaw) {
-    // "world" convention of the reference (rbox.py:87-95): length h along +x, width w along y at yaw 0
-    const double hx = 0.5 * h, hy = 0.5 * w, c = cos(yaw), s = sin(yaw);
-    const double lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};  // counter-clockwise
+// corners of a box whose heading has cosine c and sine s: "world" convention of the reference (rbox.py:87-95): length h along +x, width w
+// along y at yaw 0; counter-clockwise
+__device__ __forceinline__ Quad corners_cs(double cx, double cy, double w, double h, double c, double s) {
+    const double hx = 0.5 * h, hy = 0.5 * w;
+    const double lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};
     Quad q;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -120,75 +121,108 @@ __device__ __forceinline__ Quad corners_of(double cx, double cy, double w, doubl
     return q;
 }
 
-// Sutherland-Hodgman: clip polygon (<= 8 vertices) against the 4 half-planes of quad B.  The two vertex lists
-// ping-pong in LDS (vertex-major, one column per thread: dynamic indexing without scratch memory); the signed
-// distance of a vertex is computed once and carried to the next edge test.  Same expressions, same order as
-// oracle/warp_oracle.c.
+// Sutherland-Hodgman: clip polygon A (<= 8 vertices) against the 4 half-planes of quad B; same expressions, same order as
+// oracle/warp_oracle.c except that the one quotient of a crossing is a reciprocal with two Newton steps (<= 2 ulp).  Few pairs of a tracker
+// step get here -- a handful of lanes of a wave, if any -- so the kernel's duration IS this dependent chain.  What keeps it short:
+//   * a pass reads its (at most 8) vertices -- (x, y) pairs, ONE list per lane in LDS -- with one batch of 16-byte LDS reads into registers,
+//     walks them with static indices and writes its output over the same list (everything it needs of the old one is in registers);
+//     round 3 read vertex by vertex, one LDS round trip per step of the walk, and kept two lists per lane: 16 KB per workgroup, so that the
+//     4,096 workgroups of a 512 x 512 launch took 1.6 rounds; with 8 KB they are all resident at once;
+//   * one sincos per box, and none at all for the tracker step's detection (its heading comes from a direction vector).
+// (Compacting the clipping lanes into 8 list slots -- 2 KB of LDS per wave -- was measured too: 2 us faster when few lanes clip, 4 x slower when
+// all 64 do, chunk after chunk.  Not kept.)
 constexpr int kIouThreads = 64;
-__device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B, double* __restrict__ lds, int tid) {
-    auto P = [&](int buf, int xy, int k) -> double& { return lds[((buf * 2 + xy) * 8 + k) * kIouThreads + tid]; };
+constexpr int kClipSlots = kIouThreads;  // one vertex list per lane
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double rcp_full_of(double z) {
+    double r = __builtin_amdgcn_rcp(z);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B, d2* __restrict__ lds, int slot) {
+    auto P = [&](int k) -> d2& { return lds[k * kClipSlots + slot]; };
+    double vx[8], vy[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        P(0, 0, i) = A.x[i];
-        P(0, 1, i) = A.y[i];
-    }
-    int cur = 0, n = 4;
+    for (int i = 0; i < 4; i++) vx[i] = A.x[i], vy[i] = A.y[i];
+#pragma unroll
+    for (int i = 4; i < 8; i++) vx[i] = 0.0, vy[i] = 0.0;
+    int n = 4;
+#pragma unroll 1
     for (int e = 0; e < 4 && n > 0; e++) {
         const int e1 = (e + 1) & 3;
         const double bx = B.x[e], by = B.y[e];
         const double ex = B.x[e1] - bx, ey = B.y[e1] - by;
+        if (e > 0) {  // the list the previous pass wrote: one batch of reads (entries beyond n are stale and never used)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const d2 v = P(k);
+                vx[k] = v.x, vy[k] = v.y;
+            }
+            asm volatile("" ::: "memory");  // (the writes below go to the SAME list: they stay behind these reads)
+        }
+        double dist[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dist[k] = ex * (vy[k] - by) - ey * (vx[k] - bx);
         int m = 0;
-        double xi = P(cur, 0, 0), yi = P(cur, 1, 0);
-        double di = ex * (yi - by) - ey * (xi - bx);
-        for (int i = 0; i < n; i++) {
-            const int j = (i + 1 == n) ? 0 : i + 1;
-            const double xj = P(cur, 0, j), yj = P(cur, 1, j);
-            const double dj = ex * (yj - by) - ey * (xj - bx);
-            if (di >= 0) {
-                P(cur ^ 1, 0, m) = xi;
-                P(cur ^ 1, 1, m) = yi;
-                m++;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i < n) {
+                const bool last = i + 1 == n;
+                const double xi = vx[i], yi = vy[i], di = dist[i];
+                const double xj = last ? vx[0] : vx[(i + 1) & 7], yj = last ? vy[0] : vy[(i + 1) & 7], dj = last ? dist[0] : dist[(i + 1) & 7];
+                if (di >= 0) {
+                    const d2 v = {xi, yi};
+                    P(m) = v;
+                    m++;
+                }
+                if ((di >= 0) != (dj >= 0)) {
+                    const double t = di * rcp_full_of(di - dj);
+                    const d2 v = {xi + t * (xj - xi), yi + t * (yj - yi)};
+                    P(m) = v;
+                    m++;
+                }
             }
-            if ((di >= 0) != (dj >= 0)) {
-                const double t = di / (di - dj);
-                P(cur ^ 1, 0, m) = xi + t * (xj - xi);
-                P(cur ^ 1, 1, m) = yi + t * (yj - yi);
-                m++;
-            }
-            xi = xj, yi = yj, di = dj;
         }
         n = m;
-        cur ^= 1;
+        asm volatile("" ::: "memory");
     }
     if (n < 3) return 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const d2 v = P(k);
+        vx[k] = v.x, vy[k] = v.y;
+    }
     double a = 0.0;
-    double xi = P(cur, 0, 0), yi = P(cur, 1, 0);
-    for (int i = 0; i < n; i++) {
-        const int j = (i + 1 == n) ? 0 : i + 1;
-        const double xj = P(cur, 0, j), yj = P(cur, 1, j);
-        a += xi * yj - xj * yi;
-        xi = xj, yi = yj;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < n) {
+            const bool last = i + 1 == n;
+            const double xj = last ? vx[0] : vx[(i + 1) & 7], yj = last ? vy[0] : vy[(i + 1) & 7];
+            a += vx[i] * yj - xj * vy[i];
+        }
     }
     return fabs(0.5 * a);
 }
 
-// IoU of box A with box B, both [cx, cy, w, h, yaw] in float64.  First a rejection test that needs no square root and no sin / cos:
-// the circumscribed circles have diameters sqrt(w^2 + h^2), and ((da + db) / 2)^2 <= (da^2 + db^2) / 2, so centres further apart than
-// that bound belong to boxes that cannot intersect -- the clip would return exactly 0 for them, which is what is returned.  In a tracker
-// step almost every pair ends there (round 3 spent two float64 square roots on every pair before it could say so; the 1e-4 margin keeps
-// near-touching pairs on the exact path; NaNs fall through to it as well).  Only pairs that may touch build their corners (sin / cos)
-// and clip.  `A` is produced by `box_a()` only when needed: the tracker step's detection yaw costs a sincos and an atan2.
-template <typename BoxA>
-__device__ __forceinline__ double pair_iou(double acx, double acy, double aw, double ah, BoxA&& box_a, const double (&B)[5], double* __restrict__ lds, int tid) {
+// IoU of box A with box B, centres / sizes in float64.  First a rejection test that needs no square root and no sin / cos: the
+// circumscribed circles have diameters sqrt(w^2 + h^2), and ((da + db) / 2)^2 <= (da^2 + db^2) / 2, so centres further apart than that
+// bound belong to boxes that cannot intersect -- the clip would return exactly 0 for them, which is what is returned.  In a tracker step
+// almost every pair ends there (the 1e-4 margin keeps near-touching pairs on the exact path; NaNs fall through to it as well).  The lanes
+// that remain build their corners (`heading_a(c, s)` supplies the cosine and sine of A's heading only now: the tracker step derives them
+// from the detection's direction vector) and clip.
+template <typename HeadingA>
+__device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, double aw, double ah, HeadingA&& heading_a, const double (&B)[5], d2* __restrict__ lds) {
     const double dx = acx - B[0], dy = acy - B[1];
     const double da2 = aw * aw + ah * ah, db2 = B[2] * B[2] + B[3] * B[3];
     const double area = fabs(aw * ah) + fabs(B[2] * B[3]);
-    if (dx * dx + dy * dy > 0.5 * (da2 + db2) * 1.0001 && area > 0) return 0.0;
-    double A[5];
-    box_a(A);
-    const Quad QA = corners_of(A[0], A[1], A[2], A[3], A[4]);
-    const Quad QB = corners_of(B[0], B[1], B[2], B[3], B[4]);
-    const double inter = intersection_area(QA, QB, lds, tid);
+    if (!valid || (dx * dx + dy * dy > 0.5 * (da2 + db2) * 1.0001 && area > 0)) return 0.0;
+    double ca, sa, cb, sb;
+    heading_a(ca, sa);
+    sincos(B[4], &sb, &cb);
+    const Quad QA = corners_cs(acx, acy, aw, ah, ca, sa);
+    const Quad QB = corners_cs(B[0], B[1], B[2], B[3], cb, sb);
+    const double inter = intersection_area(QA, QB, lds, (int)(threadIdx.x & (kIouThreads - 1)));
     const double uni = area - inter;
     return uni > 0 ? inter / uni : 0.0;
 }
@@ -196,18 +230,16 @@ __device__ __forceinline__ double pair_iou(double acx, double acy, double aw, do
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
-    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];  // 16 KiB: two vertex lists per thread
+    __shared__ d2 s_poly[8 * kClipSlots];  // 8 KiB: one vertex list per lane
     const int j = blockIdx.x * blockDim.x + threadIdx.x;  // column (box of b) -> coalesced stores
     const int i = blockIdx.y;
-    if (j >= nb) return;
+    const bool valid = j < nb;
     const T* pa = a + (int64_t)i * sa;
-    const T* pb = b + (int64_t)j * sb;
+    const T* pb = b + (int64_t)(valid ? j : 0) * sb;
     const double A[5] = {(double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]};
     const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
-    out[(int64_t)i * nb + j] = (T)pair_iou(A[0], A[1], A[2], A[3], [&](double (&o)[5]) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) o[k] = A[k];
-    }, B, s_poly, (int)threadIdx.x);
+    const double v = pair_iou(valid, A[0], A[1], A[2], A[3], [&](double& c, double& s_) { sincos(A[4], &s_, &c); }, B, s_poly);
+    if (valid) out[(int64_t)i * nb + j] = (T)v;
 }
 
 // ---- rotated boxes through a similarity H (reference bev/rbox.py:173-219) ------------------------------------------
@@ -244,38 +276,25 @@ __global__ __launch_bounds__(256) void rbox_transform_kernel(const T* __restrict
 }
 
 // ---- one tracker step in one launch (reference bev/tool/rbox_tracking_BrnoCompSpeed.py:88-109 with the association
-// front-end of bev/tracker/rbox_tracker.py:383-405): block (jb, i) scores detection i against 64 predicted tracker boxes and writes the
-// IoU row segment and the `iou > threshold` gate; block (0, i) also writes the world box and its image-plane centre (rbox_world_img,
-// rbox.py:221-226).  What a pair needs first is only the detection's world CENTRE and SIZE (two divisions): the yaw -- a sincos and an
-// atan2, the long dependent chain round 3 ran in thread 0 of every block before anybody could start -- is needed by the few pairs that
-// survive the rejection test and by block (0, i)'s output, and is computed there (after the pairs have been scored and stored).
+// front-end of bev/tracker/rbox_tracker.py:383-405): SCORING workgroup (jb, i), i < n, scores detection i against 64 predicted tracker
+// boxes and writes the IoU row segment and the `iou > threshold` gate; OUTPUT workgroups (rows n .. of the grid) write the world boxes and
+// their image-plane centres (rbox_world_img, rbox.py:221-226), 64 detections each.  What a pair needs first is only the detection's world
+// CENTRE and SIZE (two divisions): the yaw -- a sincos and an atan2, the long dependent chain round 3 ran in thread 0 of every workgroup
+// before anybody could start -- is needed by the few pairs that survive the rejection test (as a direction vector) and by the outputs.
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __restrict__ dets, int n, int sd, const T* __restrict__ trks, int m, int st,
                                                                    const SimH Hwb, const H9 Him, int has_img, double thr, T* __restrict__ dets_world,
                                                                    T* __restrict__ iou, uint8_t* __restrict__ cand, T* __restrict__ dets_img) {
-    __shared__ double s_poly[2 * 2 * 8 * kIouThreads];
-    const int i = blockIdx.y, tid = (int)threadIdx.x;
-    const int j = blockIdx.x * blockDim.x + tid;
-    const T* pd = dets + (int64_t)i * sd;
-    // centre and size of the detection in the world, as box_through computes them (every lane: the same scalars, no LDS round trip);
-    // rounded to the storage type like the dets_world output -- the box the tracker would see
-    const double x = (double)pd[0], y = (double)pd[1];
-    const double X = Hwb.h[0] * x + Hwb.h[1] * y + Hwb.h[2], Y = Hwb.h[3] * x + Hwb.h[4] * y + Hwb.h[5], W = Hwb.h[6] * x + Hwb.h[7] * y + Hwb.h[8];
-    const double acx = (double)(T)(X / W), acy = (double)(T)(Y / W), aw = (double)(T)((double)pd[2] * Hwb.scale), ah = (double)(T)((double)pd[3] * Hwb.scale);
-    if (j < m) {
-        const T* pb = trks + (int64_t)j * st;
-        const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
-        const double v = pair_iou(acx, acy, aw, ah, [&](double (&o)[5]) {
-            box_through<T>(pd, Hwb, 1, o);
-#pragma unroll
-            for (int k = 0; k < 5; k++) o[k] = (double)(T)o[k];
-        }, B, s_poly, tid);
-        iou[(int64_t)i * m + j] = (T)v;
-        cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);
-    }
-    if (blockIdx.x == 0 && tid == 0) {
+    __shared__ d2 s_poly[8 * kClipSlots];
+    const int tid = (int)threadIdx.x;
+    if ((int)blockIdx.y >= n) {
+        // OUTPUT workgroups (rows n .. of the grid, column 0 only): lane l writes the world box and the image-plane centre of detection
+        // 64 (blockIdx.y - n) + l.  The yaw's sincos + atan2 chain runs here, 64 detections at a time, beside the scoring workgroups --
+        // round 3 ran it in lane 0 of every scoring workgroup, in front of the pairs.
+        const int i = ((int)blockIdx.y - n) * kIouThreads + tid;
+        if (blockIdx.x != 0 || i >= n) return;
         double o[5];
-        box_through<T>(pd, Hwb, 1, o);
+        box_through<T>(dets + (int64_t)i * sd, Hwb, 1, o);
 #pragma unroll
         for (int k = 0; k < 5; k++) dets_world[(int64_t)i * 5 + k] = (T)o[k];
         if (has_img) {
@@ -284,6 +303,33 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
             dets_img[(int64_t)i * 2] = (T)(Xi / Wi);
             dets_img[(int64_t)i * 2 + 1] = (T)(Yi / Wi);
         }
+        return;
+    }
+    if (m <= 0) return;
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + tid;
+    const bool valid = j < m;
+    const T* pd = dets + (int64_t)i * sd;
+    // centre and size of the detection in the world, as box_through computes them (every lane: the same scalars, no LDS round trip);
+    // rounded to the storage type like the dets_world output -- the box the tracker would see
+    const double x = (double)pd[0], y = (double)pd[1];
+    const double X = Hwb.h[0] * x + Hwb.h[1] * y + Hwb.h[2], Y = Hwb.h[3] * x + Hwb.h[4] * y + Hwb.h[5], W = Hwb.h[6] * x + Hwb.h[7] * y + Hwb.h[8];
+    const double acx = (double)(T)(X / W), acy = (double)(T)(Y / W), aw = (double)(T)((double)pd[2] * Hwb.scale), ah = (double)(T)((double)pd[3] * Hwb.scale);
+    const T* pb = trks + (int64_t)(valid ? j : 0) * st;
+    const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
+    const double v = pair_iou(valid, acx, acy, aw, ah, [&](double& c, double& s_) {
+        // The world heading of a BEV detection is the direction H gives its (sin yaw, cos yaw) vector (angle_world_bev, rbox.py:162-171):
+        // its cosine and sine are that vector normalised -- no atan2 followed by a sincos of the result.  (For float32 boxes this is the
+        // heading BEFORE the yaw is rounded to float32 for dets_world: 6e-8 rad, inside the 2e-6 the float32 IoU is compared at.)
+        double sn, cs;
+        sincos((double)pd[4], &sn, &cs);
+        const double tx = Hwb.h[0] * sn + Hwb.h[1] * cs, ty = Hwb.h[3] * sn + Hwb.h[4] * cs;
+        const double inv = 1.0 / sqrt(tx * tx + ty * ty);
+        c = tx * inv, s_ = ty * inv;
+    }, B, s_poly);
+    if (valid) {
+        iou[(int64_t)i * m + j] = (T)v;
+        cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);
     }
 }
 
@@ -469,7 +515,8 @@ hipError_t launch_tracker_step(const void* dets, int n, int det_stride, const vo
     const SimH s = make_sim(H_world_bev, scale);
     H9 him;
     for (int i = 0; i < 9; i++) him.h[i] = H_img_world ? H_img_world[i] : 0.0;
-    const dim3 block(kIouThreads), grid(m > 0 ? (m + kIouThreads - 1) / kIouThreads : 1, n);
+    // rows 0 .. n - 1: scoring workgroups (detection x 64 tracks); rows n ..: output workgroups, 64 detections each (column 0 works)
+    const dim3 block(kIouThreads), grid(m > 0 ? (m + kIouThreads - 1) / kIouThreads : 1, n + (n + kIouThreads - 1) / kIouThreads);
     if (dtype == 2)
         hipLaunchKernelGGL(tracker_step_kernel<double>, grid, block, 0, stream, (const double*)dets, n, det_stride, (const double*)trks, m, trk_stride, s, him,
                            H_img_world != nullptr, iou_threshold, (double*)dets_world, (double*)iou, cand, (double*)dets_img);

@@ -403,3 +403,49 @@ def test_composite_maps_survive_cache_churn_under_a_captured_graph():
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
     del junk
+
+
+def test_tracker_step_plan_cache_and_iou_out():
+    """The validated-launch cache of tracker_geometry_step: a second call with the same device buffers takes the bound launch and
+    sees NEW box values; other matrices (same buffers) are a different key; rbox_iou writes into a caller's tensor and checks it."""
+    from bev_amd import tracker_geom as tg
+    from bev_amd.iou import rbox_iou
+    dets_bev, trks, dets_world_host, H_world_bev, H_img_world = _tracker_case(96, 80, seed=8)
+    d, t = torch.from_numpy(dets_bev).cuda(), torch.from_numpy(trks).cuda()
+    tg._plans.clear()
+    out = tg.tracker_geometry_step(d, t, H_world_bev, 0.3, H_img_world)
+    assert not tg._plans
+    assert tg.tracker_geometry_step(d, t, H_world_bev, 0.3, H_img_world, out=out) is out and len(tg._plans) == 1
+    d2, t2, dw2, _, _ = _tracker_case(96, 80, seed=9)
+    d.copy_(torch.from_numpy(d2).cuda())
+    t.copy_(torch.from_numpy(t2).cuda())
+    assert tg.tracker_geometry_step(d, t, H_world_bev, 0.3, H_img_world, out=out) is out and len(tg._plans) == 1  # the hit
+    np.testing.assert_allclose(out["dets_world"].cpu().numpy(), dw2, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["iou"].cpu().numpy(), co.rbox_iou(out["dets_world"].cpu().numpy(), t2[:, :5]), rtol=0, atol=1e-12)
+    H2 = H_world_bev.copy()
+    H2[0, 2] += 1.0
+    tg.tracker_geometry_step(d, t, H2, 0.3, H_img_world, out=out)
+    assert len(tg._plans) == 2
+    assert abs(out["dets_world"].cpu().numpy()[:, 0] - dw2[:, 0] - 1.0).max() < 1e-9
+    with pytest.raises(ValueError):
+        tg.tracker_geometry_step(d, t, H_world_bev, 0.3, H_img_world, out={"iou": out["iou"]})
+    io = torch.empty((96, 80), dtype=torch.float64, device="cuda")
+    assert rbox_iou(out["dets_world"], t, out=io) is io
+    np.testing.assert_allclose(io.cpu().numpy(), co.rbox_iou(out["dets_world"].cpu().numpy(), t2[:, :5]), rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        rbox_iou(out["dets_world"], t, out=io[:, :40])
+    tg._plans.clear()
+
+
+def test_many_overlapping_pairs_per_wave():
+    """More lanes of a wave clip than there are vertex-list slots (kClipSlots = 8): every box of `b` is a jittered copy of ONE box, so all
+    64 lanes of a workgroup survive the rejection test and the clip runs in chunks."""
+    from bev_amd.iou import rbox_iou
+    rng = np.random.default_rng(13)
+    one = np.array([10.0, 20.0, 2.0, 5.0, 0.4])
+    a = one[None, :] + rng.normal(0, [0.3, 0.3, 0.05, 0.1, 0.2], (40, 5))
+    b = one[None, :] + rng.normal(0, [0.3, 0.3, 0.05, 0.1, 0.2], (150, 5))
+    exp = co.rbox_iou(a, b)
+    assert (exp > 0.1).mean() > 0.9
+    got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
