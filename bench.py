@@ -438,9 +438,15 @@ def oracle_check(w, frames=(0, -1)):
 def variant_line(w, steps, warmup, barrier, label=None, probe=False, check=True):
     ceiling = measured_ceiling(w) if probe else None
     el, lm = w.run(steps, warmup, barrier)
+    sclk = None
+    if probe:  # the clock THIS variant's kernel holds (the vector-ALU issue time is priced with it): 8-bit ~2.05 GHz, float ~1.7-2.0
+        try:
+            sclk = kernel_clock(w, launches=150)
+        except Exception as e:  # a diagnostic must not lose the line
+            print("kernel_clock failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
     line = {"dtype": label or w.dtype, "interp": w.interp_name, "homography": w.homography,
             "value": round(w.B * w.dw * w.dh * steps / 1e6 / el, 1), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
-            "roofline": w.roofline(lm, ceiling=ceiling)}
+            "roofline": w.roofline(lm, ceiling=ceiling, sclk_mhz=sclk)}
     if check:
         line["matches_oracle"] = oracle_check(w)
     return line
@@ -609,7 +615,7 @@ def composite_config(dev):
     return {"workload": "composite_bev_img: 1080p background + 1080p foreground + mask -> one 1024x1024 uint8 composite (device resident)",
             "one_launch_us": round(float(np.median(one)) * 1e6, 1), "three_warps_plus_blend_us": round(float(np.median(thr)) * 1e6, 1),
             "one_launch_back_to_back_us": round(one_b2b, 1), "one_u8_warp_same_destination_back_to_back_us": round(warp_b2b, 1),
-            "kernel": "warp_rows<uint8,3,linear,NSRC=3> (12 waves per workgroup; rocprofv3 kernel time: profiles/r03_geom_rocprofv3_summary.txt)",
+            "kernel": "warp_rows<uint8,3,linear,NSRC=3> (12 waves per workgroup; rocprofv3 kernel time: profiles/r04_geom_rocprofv3_summary.txt)",
             "one_launch_equals_three_warps_plus_blend": same}
 
 
