@@ -47,7 +47,11 @@ def __getattr__(name):
         # a name the reference's star-imports would have bound: look it up in the sub-packages' __all__, in the reference's order
         import importlib
         for sub in _STAR:
-            mod = _subpackage(sub)
+            try:
+                mod = _subpackage(sub)
+            except ImportError:
+                mod = None  # a sub-package whose own imports fail (no cv2, no tqdm ...) cannot supply the name: `hasattr(bev, x)` must get
+                            # an AttributeError, never an ImportError; `bev.<sub-package>` itself still raises the real reason
             if mod is None or name not in getattr(mod, "__all__", ()):
                 continue
             if hasattr(mod, name):

@@ -477,3 +477,30 @@ def test_star_exported_names_resolve_through_the_overlay(tmp_path, golden):
     assert rep["video_generator"] == "bev.io.utils" and rep["homo_vis"] == "bev.visualizer.homo_vis" and rep["kpts_eval"] == "bev.evaluator.kpts_eval"
     assert rep["homo_constr"] == "bev_amd.constructor.homo_constr"  # a star-exported name the overlay owns stays ours
     assert not rep["init_ran"] and os.path.samefile(rep["bev_file"], os.path.join(ROOT, "bev", "__init__.py")) and rep["missing"] == "AttributeError"
+
+
+def test_unknown_names_stay_attribute_errors_when_a_reference_subpackage_cannot_import(tmp_path, golden):
+    """`hasattr(bev, x)` must answer False, not raise: a co-installed reference whose `bev.io` needs a cv2 that is not there makes the
+    star-export search skip that sub-package, while `bev.io` itself keeps raising the real reason."""
+    import importlib.util
+    if importlib.util.find_spec("cv2") is not None:
+        pytest.skip("a cv2 is importable here: the stub reference's bev.io would import")
+    stubs, ref, _ = build_stubs(tmp_path, golden)
+    (stubs / "cv2.py").unlink()  # no cv2 at all: the stub reference's bev/io/utils.py imports it at the top
+    code = textwrap.dedent('''
+        import json
+        import bev
+        rep = {"has_typo": hasattr(bev, "no_such_name"), "has_homo_constr": hasattr(bev, "homo_constr"), "has_video_generator": hasattr(bev, "video_generator")}
+        try:
+            bev.io
+            rep["io"] = "imported"
+        except ImportError as e:
+            rep["io"] = type(e).__name__ + ":" + str(getattr(e, "name", ""))
+        print(json.dumps(rep))
+    ''')
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, str(stubs), str(ref)])
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep == {"has_typo": False, "has_homo_constr": True, "has_video_generator": False, "io": "ModuleNotFoundError:cv2"}
