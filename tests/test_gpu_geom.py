@@ -449,3 +449,24 @@ def test_many_overlapping_pairs_per_wave():
     assert (exp > 0.1).mean() > 0.9
     got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+
+
+def test_rbox_iou_random_scales():
+    """Boxes of very different sizes (one inside the other, slivers 1 : 3000), concentric, identical and almost identical boxes against the
+    oracle: the square-root-free rejection test must never drop a pair that intersects.  (Zero-AREA boxes are left out: the clip of the
+    oracle -- and of the kernel, where the rejection test does not end the pair first -- returns the other box's area for a degenerate
+    clip polygon, i.e. inter / (union ~ 0); what d3d does there is unknown, and the tracker never produces such boxes.)"""
+    from bev_amd.iou import rbox_iou
+    rng = np.random.default_rng(77)
+    n = 200
+    a = np.column_stack([rng.uniform(-20, 20, (n, 2)), 10 ** rng.uniform(-2, 1.5, n), 10 ** rng.uniform(-2, 1.5, n), rng.uniform(-7, 7, n)])
+    b = np.column_stack([rng.uniform(-20, 20, (n, 2)), 10 ** rng.uniform(-2, 1.5, n), 10 ** rng.uniform(-2, 1.5, n), rng.uniform(-7, 7, n)])
+    b[:20] = a[:20]                                   # identical
+    b[20:40, :2] = a[20:40, :2]                       # concentric, other size and heading
+    b[50:60] = a[50:60] + np.array([1e-9, 0, 0, 0, 0])  # almost identical
+    exp = co.rbox_iou(a, b)
+    got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.diag(got)[:20], 1.0, atol=1e-12)
+    assert (exp > 0).mean() > 0.02  # the clip really ran for many pairs (~1,000 of 40,000)
