@@ -17,6 +17,7 @@ snippet):
     ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
     nostagger / revrows / lpt   dispatch-order experiments: no XCD stagger / a frame's tile rows bottom-up / an XCD walks all its frames tile row by tile row
+    waves5 / ahead1   five waves per SIMD (<= 96 VGPRs) / one tap set in flight in the straight-line bilinear tiles
     stage     interior row-affine tiles take the LDS-staged producer / consumer form (rows_staged.inc; off in the product)
     stagent   (with stage) the staged form's ring fills are non-temporal (aux = 2)
     pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
@@ -131,6 +132,10 @@ def patch(files, spec):
             "        const uint32_t fpx = (uint32_t)a.chunk / (uint32_t)a.tiles_per_frame, per_row = fpx * (uint32_t)a.tiles_x;\n"
             "        const uint32_t r = in_run / per_row, rem = in_run - r * per_row, f = rem / (uint32_t)a.tiles_x;\n"
             "        frame_idx = (blockIdx.x & 7u) * fpx + f;\n        t = r * (uint32_t)a.tiles_x + (rem - f * (uint32_t)a.tiles_x);\n    }\n")
+    elif spec == "waves5":  # every warp kernel compiled for five waves per SIMD (<= 96 VGPRs)
+        rep("constexpr int kWavesPerSimd = 4;", "constexpr int kWavesPerSimd = 5;")
+    elif spec == "ahead1":  # bilinear straight-line tiles with ONE tap set in flight
+        rep("constexpr int kAhead = INTERP == kNearest ? kFull : 2;", "constexpr int kAhead = INTERP == kNearest ? kFull : 1;")
     elif spec == "stage":
         rep("    constexpr bool kStageEnabled = false;", "    constexpr bool kStageEnabled = true;")
     elif spec == "stagent":
