@@ -436,7 +436,11 @@ hipError_t launch_project_points(const void* in, void* out, int64_t n, int dim, 
     const int vec16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     const int block = 256;
     const int64_t want = (n + block - 1) / block;
-    const int grid = (int)(want < 256 * 8 ? want : 256 * 8);  // grid-stride above 8 blocks per CU
+    // float32 (two points per lane and step): grid-stride above 8 workgroups per CU; float64 (one point per lane): a workgroup per 256
+    // points and no loop at all -- A/B of the grid caps 8 / 16 / 32 per CU / none, round 4 (profiles/r04_points_ab.txt): float32 within
+    // 1 % of each other (none: -5 %), float64 5.43 / 5.62 / 5.71 / 5.89 TB/s
+    const int64_t cap = dtype == 2 ? (int64_t)1 << 30 : 256 * 8;
+    const int grid = (int)(want < cap ? want : cap);
     if (dtype == 2) {
         if (dim == 2)
             hipLaunchKernelGGL((project_points_kernel<double, 2>), dim3(grid), dim3(block), 0, stream, (const double*)in, (double*)out, n, h, vec16);
