@@ -17,6 +17,7 @@ snippet):
     ownrow / ownblk   every tile forced to the unturned (row segments; edge tiles: blocks) / turned (patches) lane layout: the slant rule's A/B
     fillall / edgefill / infill   all / edge / interior tiles cost what outside tiles cost
     nostagger / revrows / lpt   dispatch-order experiments: no XCD stagger / a frame's tile rows bottom-up / an XCD walks all its frames tile row by tile row
+    waves3 / ahead3 / ahead4   three waves per SIMD (<= 168 VGPRs) / three or four tap sets in flight
     waves5 / ahead1   five waves per SIMD (<= 96 VGPRs) / one tap set in flight in the straight-line bilinear tiles
     stage     interior row-affine tiles take the LDS-staged producer / consumer form (rows_staged.inc; off in the product)
     stagent   (with stage) the staged form's ring fills are non-temporal (aux = 2)
@@ -134,6 +135,11 @@ def patch(files, spec):
             "        frame_idx = (blockIdx.x & 7u) * fpx + f;\n        t = r * (uint32_t)a.tiles_x + (rem - f * (uint32_t)a.tiles_x);\n    }\n")
     elif spec == "waves5":  # every warp kernel compiled for five waves per SIMD (<= 96 VGPRs)
         rep("constexpr int kWavesPerSimd = 4;", "constexpr int kWavesPerSimd = 5;")
+    elif spec == "waves3":  # three waves per SIMD (<= 168 VGPRs): room for a third tap set
+        rep("constexpr int kWavesPerSimd = 4;", "constexpr int kWavesPerSimd = 3;")
+        rep("amdgpu_waves_per_eu(NSRC > 1 ? 3 : kWavesPerSimd, 8)", "amdgpu_waves_per_eu(3, 3)")  # (max = 3 too: otherwise the allocator still aims at four waves)
+    elif spec in ("ahead3", "ahead4"):  # bilinear straight-line tiles with three / four tap sets in flight
+        rep("constexpr int kAhead = INTERP == kNearest ? kFull : 2;", "constexpr int kAhead = INTERP == kNearest ? kFull : %s;" % spec[5:])
     elif spec == "ahead1":  # bilinear straight-line tiles with ONE tap set in flight
         rep("constexpr int kAhead = INTERP == kNearest ? kFull : 2;", "constexpr int kAhead = INTERP == kNearest ? kFull : 1;")
     elif spec == "stage":
