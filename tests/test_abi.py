@@ -163,3 +163,38 @@ def test_tracker_step_validates_before_touching_the_device(lib):
     assert call(a1=0) == 0                        # nothing to do: no launch, no device
     assert lib.bevwarp_rbox_transform(one, 0, 5, H, 1, one, _lib.F64, None) == 0
     assert lib.bevwarp_rbox_transform(one, 3, 4, H, 1, one, _lib.F64, None) == -1
+
+
+def test_overlap_guard_has_no_false_negatives(lib):
+    """The overlap guard of bevwarp_warp against brute force: 3,000 seeded random layouts (1-channel uint8, tiny images, arbitrary strides,
+    1-3 frames) of a source and a destination inside one address range.  Whenever a source byte IS a destination byte the call must be
+    refused (-6); it may be refused conservatively when they are not -- except for the side-by-side case the refinement exists for.
+    No device is touched: calls that pass the guard fail next on a NaN border value (-4)."""
+    rng = np.random.default_rng(5)
+    nan_border = ctypes.cast((ctypes.c_double * 1)(float("nan")), ctypes.c_void_p)
+    one = ctypes.c_void_p(16)
+    accepted = refused_disjoint = 0
+    for _ in range(3000):
+        sw, sh, dw, dh = (int(v) for v in rng.integers(1, 7, 4))
+        batch = int(rng.integers(1, 4))
+        if rng.random() < 0.5:  # the refinement's class: one common row stride, frame strides multiples of it
+            rs = int(rng.integers(max(sw, dw), 20))
+            srs = drs = rs
+            sfs, dfs = rs * int(rng.integers(sh, sh + 3)), rs * int(rng.integers(dh, dh + 3))
+        else:
+            srs, drs = int(rng.integers(sw, 20)), int(rng.integers(dw, 20))
+            sfs, dfs = int(rng.integers(sh * srs, sh * srs + 30)), int(rng.integers(dh * drs, dh * drs + 30))
+        s0, d0 = 4096 + int(rng.integers(0, 120)), 4096 + int(rng.integers(0, 120))
+        sbytes = {s0 + f * sfs + r * srs + c for f in range(batch) for r in range(sh) for c in range(sw)}
+        dbytes = {d0 + f * dfs + r * drs + c for f in range(batch) for r in range(dh) for c in range(dw)}
+        st = lib.bevwarp_warp(ctypes.c_void_p(s0), ctypes.c_void_p(d0), batch, sh, sw, dh, dw, 1, sfs, srs, dfs, drs, one, 1, _lib.U8, 1, nan_border, None)
+        assert st in (-4, -6), st
+        if sbytes & dbytes:
+            assert st == -6, (s0, d0, sw, sh, dw, dh, batch, srs, drs, sfs, dfs)
+        elif st == -4:
+            accepted += 1
+        else:
+            refused_disjoint += 1
+    assert accepted > 300  # the guard is not simply refusing everything (bounding ranges apart, or side-by-side columns)
+    # a side-by-side pair is accepted even though the bounding ranges interleave
+    assert lib.bevwarp_warp(ctypes.c_void_p(4096), ctypes.c_void_p(4096 + 6), 2, 4, 6, 4, 6, 1, 64, 16, 64, 16, one, 1, _lib.U8, 1, nan_border, None) == -4
