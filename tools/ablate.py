@@ -23,6 +23,7 @@ snippet):
     stagent   (with stage) the staged form's ring fills are non-temporal (aux = 2)
     pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
     ntstore   the wide destination stores are non-temporal
+    stsc1 / stsc01   the wide destination stores carry the sc1 / sc0 sc1 cache policy (write-through)
     ring16 / ring4   the staged form's ring holds 16 / 4 source rows instead of 8
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
@@ -121,6 +122,11 @@ def patch(files, spec):
     elif spec in ("pwfix", "pws5"):  # the producer's wave index: always wave 3 / rotating with the dispatch order divided by the CUs of an XCD
         rep("const int p_wave = (int)((blockIdx.x >> 3) & (uint32_t)(kWaves - 1));",
             "const int p_wave = 3;" if spec == "pwfix" else "const int p_wave = (int)((blockIdx.x >> 8) & (uint32_t)(kWaves - 1));")
+    elif spec in ("stsc1", "stsc01"):  # the wide destination stores with the sc1 (write-through) / sc0 sc1 cache policy, as inline assembly
+        pol = "sc1" if spec == "stsc1" else "sc0 sc1"
+        rep("    *p = v;\n}", "    if constexpr (__builtin_vectorelements(V) == 4)\n        asm volatile(\"global_store_dwordx4 %%0, %%1, off %s\" ::\"v\"(p), \"v\"(v) : \"memory\");\n"
+            "    else if constexpr (__builtin_vectorelements(V) == 3)  // (a 3-element vector is padded to 16 bytes: count elements, not bytes)\n"
+            "        asm volatile(\"global_store_dwordx3 %%0, %%1, off %s\" ::\"v\"(p), \"v\"(v) : \"memory\");\n    else\n        *p = v;\n}" % (pol, pol))
     elif spec == "nostagger":  # every XCD starts at the first item of its run
         rep("    uint32_t in_run = seq + (blockIdx.x & 7u) * (uint32_t)a.stagger;", "    uint32_t in_run = seq;")
     elif spec == "revrows":  # a frame's tile rows from the bottom up
