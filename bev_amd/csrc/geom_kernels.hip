@@ -147,12 +147,16 @@ __device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B
     for (int i = 0; i < 4; i++) vx[i] = A.x[i], vy[i] = A.y[i];
 #pragma unroll
     for (int i = 4; i < 8; i++) vx[i] = 0.0, vy[i] = 0.0;
+    // B's corners rotate through four register pairs, one step per pass: indexing them with the pass number put the quad into scratch
+    // memory (72 bytes per lane, four scratch loads at the head of every pass, and a scratch allocation for every wave of the launch)
+    double qx[4] = {B.x[0], B.x[1], B.x[2], B.x[3]}, qy[4] = {B.y[0], B.y[1], B.y[2], B.y[3]};
     int n = 4;
 #pragma unroll 1
     for (int e = 0; e < 4 && n > 0; e++) {
-        const int e1 = (e + 1) & 3;
-        const double bx = B.x[e], by = B.y[e];
-        const double ex = B.x[e1] - bx, ey = B.y[e1] - by;
+        const double bx = qx[0], by = qy[0];
+        const double ex = qx[1] - bx, ey = qy[1] - by;
+        qx[0] = qx[1], qx[1] = qx[2], qx[2] = qx[3], qx[3] = bx;
+        qy[0] = qy[1], qy[1] = qy[2], qy[2] = qy[3], qy[3] = by;
         if (e > 0) {  // the list the previous pass wrote: one batch of reads (entries beyond n are stale and never used)
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -324,7 +328,10 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
         double sn, cs;
         sincos((double)pd[4], &sn, &cs);
         const double tx = Hwb.h[0] * sn + Hwb.h[1] * cs, ty = Hwb.h[3] * sn + Hwb.h[4] * cs;
-        const double inv = 1.0 / sqrt(tx * tx + ty * ty);
+        const double q = tx * tx + ty * ty;  // 1 / sqrt(q): the hardware estimate and two Newton steps (<= 2 ulp; a square root and a quotient cost four times that)
+        double inv = __builtin_amdgcn_rsq(q);
+        inv = __builtin_fma(0.5 * inv, __builtin_fma(-q * inv, inv, 1.0), inv);
+        inv = __builtin_fma(0.5 * inv, __builtin_fma(-q * inv, inv, 1.0), inv);
         c = tx * inv, s_ = ty * inv;
     }, B, s_poly);
     if (valid) {

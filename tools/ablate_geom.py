@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Ablation builds of the IoU / tracker-step kernels (measurement aid; the product source carries no ablation code).
+
+    python tools/ablate_geom.py <name>=<spec>[+<spec>...] ...   ->  bev_amd/csrc/variants/<name>.so   (time with tools/time_tracker.py)
+
+Specs patch a COPY of bev_amd/csrc/geom_kernels.hip:
+    wg256      256 lanes (4 waves) per workgroup instead of 64: a quarter of the workgroups to dispatch
+    wg128      128 lanes per workgroup
+    noclip     (timing only) the clip returns after the corners: what is left is launch + loads + rejection + sincos + stores
+    rejectall  (timing only) every pair ends at the rejection test: launch + loads + stores
+    empty      (timing only) the scoring lanes store 0 without reading a box: the launch floor of this grid
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bev_amd", "csrc")
+FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-undefined-internal".split()
+
+
+def patch(text, spec):
+    def rep(old, new, count=1):
+        nonlocal text
+        assert text.count(old) >= 1, (spec, old[:70])
+        text = text.replace(old, new, count)
+    if spec in ("wg256", "wg128"):
+        rep("constexpr int kIouThreads = 64;", "constexpr int kIouThreads = %s;" % spec[2:])
+    elif spec == "noclip":
+        rep("    int n = 4;\n#pragma unroll 1\n    for (int e = 0; e < 4 && n > 0; e++) {",
+            "    int n = 4;\n    { double acc = 0; for (int i = 0; i < 4; i++) acc += A.x[i] * B.y[i] - A.y[i] * B.x[i]; if (acc != 1.2345e300) return acc * 1e-300; }\n"
+            "#pragma unroll 1\n    for (int e = 0; e < 4 && n > 0; e++) {")
+    elif spec == "rejectall":
+        rep("&& area > 0)) return 0.0;", "&& area > 0) || area != 1.2345e300) return 0.0;")
+    elif spec == "empty":
+        rep("    const T* pa = a + (int64_t)i * sa;\n", "    if (na != 123456789) { if (valid) out[(int64_t)i * nb + j] = (T)0; return; }\n    const T* pa = a + (int64_t)i * sa;\n")
+        rep("    const T* pd = dets + (int64_t)i * sd;\n", "    if (n != 123456789) { if (valid) { iou[(int64_t)i * m + j] = (T)0; cand[(int64_t)i * m + j] = 0; } return; }\n"
+            "    const T* pd = dets + (int64_t)i * sd;\n")
+    else:
+        raise SystemExit("unknown spec %r" % spec)
+    return text
+
+
+def main():
+    os.makedirs(os.path.join(CSRC, "variants"), exist_ok=True)
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
+    for arg in sys.argv[1:]:
+        name, _, specs = arg.partition("=")
+        text = open(os.path.join(CSRC, "geom_kernels.hip")).read()
+        for s in (specs or name).split("+"):
+            text = patch(text, s)
+        d = "/tmp/ablate_geom_%s" % name
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "geom_kernels.hip"), "w") as f:
+            f.write(text)
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(d, "geom_kernels.hip"),
+                               "-o", os.path.join(d, "geom_kernels.o")])
+        objs = [os.path.join(CSRC, o) for o in sorted(os.listdir(CSRC)) if o.endswith(".o") and o != "geom_kernels.o"]
+        out = os.path.join(CSRC, "variants", name + ".so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, os.path.join(d, "geom_kernels.o")] + objs)
+        print("built", out)
+
+
+if __name__ == "__main__":
+    main()
