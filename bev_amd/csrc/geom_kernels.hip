@@ -103,120 +103,70 @@ __global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out
 }
 
 // ---- rotated-rectangle IoU ------------------------------------------------------------------------
-struct Quad {
-    double x[4], y[4];
-};
-
-// corners of a box whose heading has cosine c and sine s: "world" convention of the reference (rbox.py:87-95): length h along +x, width w
-// along y at yaw 0; counter-clockwise
-__device__ __forceinline__ Quad corners_cs(double cx, double cy, double w, double h, double c, double s) {
-    const double hx = 0.5 * h, hy = 0.5 * w;
-    const double lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};
-    Quad q;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        q.x[i] = c * lx[i] - s * ly[i] + cx;
-        q.y[i] = s * lx[i] + c * ly[i] + cy;
-    }
-    return q;
-}
-
-// Sutherland-Hodgman: clip polygon A (<= 8 vertices) against the 4 half-planes of quad B; same expressions, same order as
-// oracle/warp_oracle.c except that the one quotient of a crossing is a reciprocal with two Newton steps (<= 2 ulp).  Few pairs of a tracker
-// step get here -- a handful of lanes of a wave, if any -- so the kernel's duration IS this dependent chain.  What keeps it short:
-//   * a pass reads its (at most 8) vertices -- (x, y) pairs, ONE list per lane in LDS -- with one batch of 16-byte LDS reads into registers,
-//     walks them with static indices and writes its output over the same list (everything it needs of the old one is in registers);
-//     round 3 read vertex by vertex, one LDS round trip per step of the walk, and kept two lists per lane: 16 KB per workgroup, so that the
-//     4,096 workgroups of a 512 x 512 launch took 1.6 rounds; with 8 KB they are all resident at once;
-//   * one sincos per box, and none at all for the tracker step's detection (its heading comes from a direction vector).
-// (Compacting the clipping lanes into 8 list slots -- 2 KB of LDS per wave -- was measured too: 2 us faster when few lanes clip, 4 x slower when
-// all 64 do, chunk after chunk.  Not kept.)
+// Area of (box A) n (box B) without clipping a vertex list.  In B's own frame B is the axis-aligned box |x| <= hx, |y| <= hy, and the map
+// C(x, y) = (clamp(x, -hx, hx), clamp(y, -hy, hy)) is the identity inside it and flattens everything outside onto its border (Jacobian 1
+// inside, 0 outside), so the area enclosed by the IMAGE C(dA) of A's outline is exactly area(A n B).  The image of a straight edge
+// p -> p + d is piecewise straight with corners only where the edge meets one of the four lines x = +-hx, y = +-hy: parameters
+// t = (+-hx - px) / dx, (+-hy - py) / dy.  So per edge: the four parameters, sorted and clamped to [0, 1]; the image points at 0, the four,
+// 1; five shoelace terms.  Every edge is independent of the others and the code is straight-line: no vertex lists in LDS, no branches, no
+// loop-carried chain -- the Sutherland-Hodgman walk this replaces (rounds 1-4; it is what oracle/warp_oracle.c still does) was a serial
+// chain of ~600 dependent float64 instructions that lasted 4 of the kernel's 8 us although only a few lanes of a wave ever ran it.
+// Robust by construction: a parameter that is wrong (dx ~ 0: reciprocal overflows to inf / NaN, the clamps turn it into 0 or 1) only adds
+// a corner ON the edge or misplaces a true one by no more than the edge's distance from that line, i.e. by rounding error; touching and
+// coincident edges need no tie rules.  Agreement with the oracle's clip: <= 1e-13 on the IoU (tests: 1e-12).
 constexpr int kIouThreads = 64;
-constexpr int kClipSlots = kIouThreads;  // one vertex list per lane
-typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double rcp_full_of(double z) {
     double r = __builtin_amdgcn_rcp(z);
     r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ double intersection_area(const Quad& A, const Quad& B, d2* __restrict__ lds, int slot) {
-    auto P = [&](int k) -> d2& { return lds[k * kClipSlots + slot]; };
-    double vx[8], vy[8];
+__device__ __forceinline__ double clamp_sym(double v, double h) { return fmin(fmax(v, -h), h); }
+// A: centre (lx, ly) in B's frame, half-length vector (ux, uy), half-width vector (vx, vy); B: half sizes hx (length, along x), hy.
+__device__ __forceinline__ double intersection_area(double lx, double ly, double ux, double uy, double vx, double vy, double hx, double hy) {
+    // corners, counter-clockwise from (-u - v), and their images
+    const double cx[4] = {lx - ux - vx, lx + ux - vx, lx + ux + vx, lx - ux + vx}, cy[4] = {ly - uy - vy, ly + uy - vy, ly + uy + vy, ly - uy + vy};
+    double Cx[4], Cy[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) vx[i] = A.x[i], vy[i] = A.y[i];
+    for (int k = 0; k < 4; k++) Cx[k] = clamp_sym(cx[k], hx), Cy[k] = clamp_sym(cy[k], hy);
+    // edges 0 / 2 run along +-2u, edges 1 / 3 along +-2v: four reciprocals serve the sixteen parameters
+    const double iux = rcp_full_of(2.0 * ux), iuy = rcp_full_of(2.0 * uy), ivx = rcp_full_of(2.0 * vx), ivy = rcp_full_of(2.0 * vy);
+    double acc = 0.0;
 #pragma unroll
-    for (int i = 4; i < 8; i++) vx[i] = 0.0, vy[i] = 0.0;
-    // B's corners rotate through four register pairs, one step per pass: indexing them with the pass number put the quad into scratch
-    // memory (72 bytes per lane, four scratch loads at the head of every pass, and a scratch allocation for every wave of the launch)
-    double qx[4] = {B.x[0], B.x[1], B.x[2], B.x[3]}, qy[4] = {B.y[0], B.y[1], B.y[2], B.y[3]};
-    int n = 4;
-#pragma unroll 1
-    for (int e = 0; e < 4 && n > 0; e++) {
-        const double bx = qx[0], by = qy[0];
-        const double ex = qx[1] - bx, ey = qy[1] - by;
-        qx[0] = qx[1], qx[1] = qx[2], qx[2] = qx[3], qx[3] = bx;
-        qy[0] = qy[1], qy[1] = qy[2], qy[2] = qy[3], qy[3] = by;
-        if (e > 0) {  // the list the previous pass wrote: one batch of reads (entries beyond n are stale and never used)
+    for (int k = 0; k < 4; k++) {
+        const double sgn = k < 2 ? 1.0 : -1.0;
+        const double dx = sgn * 2.0 * ((k & 1) ? vx : ux), dy = sgn * 2.0 * ((k & 1) ? vy : uy);
+        const double ix = sgn * ((k & 1) ? ivx : iux), iy = sgn * ((k & 1) ? ivy : iuy);
+        const double px = cx[k], py = cy[k];
+        const double tx1 = (-hx - px) * ix, tx2 = (hx - px) * ix, ty1 = (-hy - py) * iy, ty2 = (hy - py) * iy;
+        // sorted (fmin / fmax return the other operand for a NaN), then clamped to the edge
+        const double a0 = fmin(tx1, tx2), a1 = fmax(tx1, tx2), b0 = fmin(ty1, ty2), b1 = fmax(ty1, ty2);
+        const double m1 = fmax(a0, b0), m2 = fmin(a1, b1);
+        const double t[4] = {fmin(fmax(fmin(a0, b0), 0.0), 1.0), fmin(fmax(fmin(m1, m2), 0.0), 1.0), fmin(fmax(fmax(m1, m2), 0.0), 1.0),
+                             fmin(fmax(fmax(a1, b1), 0.0), 1.0)};
+        double X0 = Cx[k], Y0 = Cy[k];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const d2 v = P(k);
-                vx[k] = v.x, vy[k] = v.y;
-            }
-            asm volatile("" ::: "memory");  // (the writes below go to the SAME list: they stay behind these reads)
-        }
-        double dist[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) dist[k] = ex * (vy[k] - by) - ey * (vx[k] - bx);
-        int m = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (i < n) {
-                const bool last = i + 1 == n;
-                const double xi = vx[i], yi = vy[i], di = dist[i];
-                const double xj = last ? vx[0] : vx[(i + 1) & 7], yj = last ? vy[0] : vy[(i + 1) & 7], dj = last ? dist[0] : dist[(i + 1) & 7];
-                if (di >= 0) {
-                    const d2 v = {xi, yi};
-                    P(m) = v;
-                    m++;
-                }
-                if ((di >= 0) != (dj >= 0)) {
-                    const double t = di * rcp_full_of(di - dj);
-                    const d2 v = {xi + t * (xj - xi), yi + t * (yj - yi)};
-                    P(m) = v;
-                    m++;
-                }
-            }
-        }
-        n = m;
-        asm volatile("" ::: "memory");
-    }
-    if (n < 3) return 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const d2 v = P(k);
-        vx[k] = v.x, vy[k] = v.y;
-    }
-    double a = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        if (i < n) {
-            const bool last = i + 1 == n;
-            const double xj = last ? vx[0] : vx[(i + 1) & 7], yj = last ? vy[0] : vy[(i + 1) & 7];
-            a += vx[i] * yj - xj * vy[i];
+        for (int i = 0; i < 5; i++) {
+            const double X1 = i < 4 ? clamp_sym(__builtin_fma(t[i & 3], dx, px), hx) : Cx[(k + 1) & 3];
+            const double Y1 = i < 4 ? clamp_sym(__builtin_fma(t[i & 3], dy, py), hy) : Cy[(k + 1) & 3];
+            acc += __builtin_fma(X0, Y1, -(X1 * Y0));
+            X0 = X1, Y0 = Y1;
         }
     }
-    return fabs(0.5 * a);
+    return fabs(0.5 * acc);
 }
 
 // IoU of box A with box B, centres / sizes in float64.  First a rejection test that needs no square root and no sin / cos: the
 // circumscribed circles have diameters sqrt(w^2 + h^2), and ((da + db) / 2)^2 <= (da^2 + db^2) / 2, so centres further apart than that
-// bound belong to boxes that cannot intersect -- the clip would return exactly 0 for them, which is what is returned.  In a tracker step
-// almost every pair ends there (the 1e-4 margin keeps near-touching pairs on the exact path; NaNs fall through to it as well).  The lanes
-// that remain build their corners (`heading_a(c, s)` supplies the cosine and sine of A's heading only now: the tracker step derives them
-// from the detection's direction vector) and clip.
+// bound belong to boxes that cannot intersect -- exactly 0 is returned for them.  In a tracker step almost every pair ends there (the 1e-4
+// margin keeps near-touching pairs on the exact path; NaNs fall through to it as well).  The lanes that remain turn A into B's frame
+// (`heading_a(c, s)` supplies the cosine and sine of A's heading only now: the tracker step derives them from the detection's direction
+// vector) and sum the contour.  Conventions of the oracle's clip that are kept: length h along the heading, width w across ("world",
+// rbox.py:87-95); an intersection below 1e-14 of the boxes' area is the rounding noise of twenty signed terms of that order and reads as 0
+// (disjoint boxes give exactly 0, as they do there); a B with ONE negative size is a clockwise clip polygon there, which clips everything
+// away: 0.
 template <typename HeadingA>
-__device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, double aw, double ah, HeadingA&& heading_a, const double (&B)[5], d2* __restrict__ lds) {
+__device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, double aw, double ah, HeadingA&& heading_a, const double (&B)[5]) {
     const double dx = acx - B[0], dy = acy - B[1];
     const double da2 = aw * aw + ah * ah, db2 = B[2] * B[2] + B[3] * B[3];
     const double area = fabs(aw * ah) + fabs(B[2] * B[3]);
@@ -224,9 +174,10 @@ __device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, d
     double ca, sa, cb, sb;
     heading_a(ca, sa);
     sincos(B[4], &sb, &cb);
-    const Quad QA = corners_cs(acx, acy, aw, ah, ca, sa);
-    const Quad QB = corners_cs(B[0], B[1], B[2], B[3], cb, sb);
-    const double inter = intersection_area(QA, QB, lds, (int)(threadIdx.x & (kIouThreads - 1)));
+    const double cr = ca * cb + sa * sb, sr = sa * cb - ca * sb;  // A's heading relative to B's
+    const double hxa = 0.5 * ah, hya = 0.5 * aw;
+    double inter = intersection_area(cb * dx + sb * dy, cb * dy - sb * dx, cr * hxa, sr * hxa, -sr * hya, cr * hya, 0.5 * fabs(B[3]), 0.5 * fabs(B[2]));
+    if (inter < 1e-14 * area || B[2] * B[3] < 0) inter = 0.0;
     const double uni = area - inter;
     return uni > 0 ? inter / uni : 0.0;
 }
@@ -234,7 +185,6 @@ __device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, d
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
-    __shared__ d2 s_poly[8 * kClipSlots];  // 8 KiB: one vertex list per lane
     const int j = blockIdx.x * blockDim.x + threadIdx.x;  // column (box of b) -> coalesced stores
     const int i = blockIdx.y;
     const bool valid = j < nb;
@@ -242,7 +192,7 @@ __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restri
     const T* pb = b + (int64_t)(valid ? j : 0) * sb;
     const double A[5] = {(double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]};
     const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
-    const double v = pair_iou(valid, A[0], A[1], A[2], A[3], [&](double& c, double& s_) { sincos(A[4], &s_, &c); }, B, s_poly);
+    const double v = pair_iou(valid, A[0], A[1], A[2], A[3], [&](double& c, double& s_) { sincos(A[4], &s_, &c); }, B);
     if (valid) out[(int64_t)i * nb + j] = (T)v;
 }
 
@@ -289,7 +239,6 @@ template <typename T>
 __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __restrict__ dets, int n, int sd, const T* __restrict__ trks, int m, int st,
                                                                    const SimH Hwb, const H9 Him, int has_img, double thr, T* __restrict__ dets_world,
                                                                    T* __restrict__ iou, uint8_t* __restrict__ cand, T* __restrict__ dets_img) {
-    __shared__ d2 s_poly[8 * kClipSlots];
     const int tid = (int)threadIdx.x;
     if ((int)blockIdx.y >= n) {
         // OUTPUT workgroups (rows n .. of the grid, column 0 only): lane l writes the world box and the image-plane centre of detection
@@ -333,7 +282,7 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
         inv = __builtin_fma(0.5 * inv, __builtin_fma(-q * inv, inv, 1.0), inv);
         inv = __builtin_fma(0.5 * inv, __builtin_fma(-q * inv, inv, 1.0), inv);
         c = tx * inv, s_ = ty * inv;
-    }, B, s_poly);
+    }, B);
     if (valid) {
         iou[(int64_t)i * m + j] = (T)v;
         cand[(int64_t)i * m + j] = (uint8_t)((double)(T)v > thr);

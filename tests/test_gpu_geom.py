@@ -438,8 +438,7 @@ def test_tracker_step_plan_cache_and_iou_out():
 
 
 def test_many_overlapping_pairs_per_wave():
-    """More lanes of a wave clip than there are vertex-list slots (kClipSlots = 8): every box of `b` is a jittered copy of ONE box, so all
-    64 lanes of a workgroup survive the rejection test and the clip runs in chunks."""
+    """Every box of `b` is a jittered copy of ONE box, so all 64 lanes of a workgroup survive the rejection test and sum a contour."""
     from bev_amd.iou import rbox_iou
     rng = np.random.default_rng(13)
     one = np.array([10.0, 20.0, 2.0, 5.0, 0.4])
@@ -451,12 +450,7 @@ def test_many_overlapping_pairs_per_wave():
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
 
 
-def test_rbox_iou_random_scales():
-    """Boxes of very different sizes (one inside the other, slivers 1 : 3000), concentric, identical and almost identical boxes against the
-    oracle: the square-root-free rejection test must never drop a pair that intersects.  (Zero-AREA boxes are left out: the clip of the
-    oracle -- and of the kernel, where the rejection test does not end the pair first -- returns the other box's area for a degenerate
-    clip polygon, i.e. inter / (union ~ 0); what d3d does there is unknown, and the tracker never produces such boxes.)"""
-    from bev_amd.iou import rbox_iou
+def _random_scale_boxes():
     rng = np.random.default_rng(77)
     n = 200
     a = np.column_stack([rng.uniform(-20, 20, (n, 2)), 10 ** rng.uniform(-2, 1.5, n), 10 ** rng.uniform(-2, 1.5, n), rng.uniform(-7, 7, n)])
@@ -464,9 +458,54 @@ def test_rbox_iou_random_scales():
     b[:20] = a[:20]                                   # identical
     b[20:40, :2] = a[20:40, :2]                       # concentric, other size and heading
     b[50:60] = a[50:60] + np.array([1e-9, 0, 0, 0, 0])  # almost identical
+    return a, b
+
+
+def test_rbox_iou_random_scales():
+    """Boxes of very different sizes (one inside the other, slivers 1 : 3000), concentric, identical and almost identical boxes: the
+    square-root-free rejection test must never drop a pair that intersects.  Two yardsticks: the oracle's float64 clip, which works in WORLD
+    coordinates and therefore carries ulp(|centre|) / size of error for centimetre boxes twenty metres from the origin (up to 8e-11 here,
+    measured against 50-digit arithmetic in tests/test_oracle_iou.py) -- agreement to 1e-12 where the smaller box side is >= 0.5 m, 2e-10
+    everywhere; and 50-digit arithmetic itself (tests/exact_iou.py) on every pair the two disagree on by more than 1e-13 plus a sample: 1e-14.
+    (Zero-AREA boxes are left out: the oracle's clip returns the other box's area for a degenerate clip polygon; what d3d does there is
+    unknown, and the tracker never produces such boxes.)"""
+    from bev_amd.iou import rbox_iou
+    a, b = _random_scale_boxes()
     exp = co.rbox_iou(a, b)
     got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
     assert np.isfinite(got).all()
-    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got, exp, rtol=0, atol=2e-10)
+    big = (np.minimum(a[:, 2], a[:, 3])[:, None] >= 0.5) & (np.minimum(b[:, 2], b[:, 3])[None, :] >= 0.5)
+    np.testing.assert_allclose(got[big], exp[big], rtol=0, atol=1e-12)
     np.testing.assert_allclose(np.diag(got)[:20], 1.0, atol=1e-12)
-    assert (exp > 0).mean() > 0.02  # the clip really ran for many pairs (~1,000 of 40,000)
+    assert (exp > 0).mean() > 0.02  # the contour sum really ran for many pairs (~1,000 of 40,000)
+    pytest.importorskip("mpmath")
+    from tests.exact_iou import iou as exact
+    pairs = {tuple(p) for p in np.argwhere(np.abs(got - exp) > 1e-13)} | {(i, i) for i in range(60)} | {tuple(p) for p in np.argwhere(exp > 0)[::8]}
+    assert len(pairs) > 100
+    for i, j in sorted(pairs):
+        assert abs(got[i, j] - exact(a[i], b[j])) <= 1e-14, (i, j, a[i], b[j])
+
+
+def test_rbox_iou_conventions_of_the_oracle_for_odd_inputs():
+    """Negative sizes are outside the reference's domain; the kernel keeps what the oracle's clip does with them (a box with ONE negative
+    size is a clockwise polygon: as the CLIP polygon it removes everything, as the clipped one it behaves like its mirror image), touching
+    boxes give exactly 0, and a NaN box gives 0."""
+    from bev_amd.iou import rbox_iou
+    rng = np.random.default_rng(5)
+    box = lambda n: np.column_stack([rng.uniform(0, 8, (n, 2)), rng.uniform(1.6, 2.2, n), rng.uniform(3.5, 6, n), rng.uniform(-np.pi, np.pi, n)])
+    a, b = box(100), box(100)
+    for m in (a, b):
+        m[:, 2] *= rng.choice([-1, 1], 100)
+        m[:, 3] *= rng.choice([-1, 1], 100)
+    got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, co.rbox_iou(a, b), rtol=0, atol=1e-12)
+    a = box(50)
+    b = a.copy()
+    b[:, 0] += a[:, 3] * np.cos(a[:, 4])  # end to end along the heading
+    b[:, 1] += a[:, 3] * np.sin(a[:, 4])
+    got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert (np.diag(got) == 0).all() and (got >= 0).all()
+    a[3, 0] = np.nan
+    got = rbox_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert np.isfinite(got).all() and (got[3] == 0).all()
