@@ -578,7 +578,8 @@ def config4(dev):
     te = event_times(step, 300, 20)
     tt = event_times(lambda: tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf), 300, 20)
     iou_out = torch.empty((512, 512), dtype=torch.float64, device=dev)
-    ti = event_times(lambda: rbox_iou(dets, trks, out=iou_out), 300, 20)
+    dets_world = buf["dets_world"].clone()  # (the IoU matrix alone: the same pairs as the step scores)
+    ti = event_times(lambda: rbox_iou(dets_world, trks, out=iou_out), 300, 20)
     from oracle import cpu_oracle as co  # checker, after the timed launches
     ok = bool(np.array_equal(outs[(k[0] - 1) % 4].cpu().numpy(), co.warp_perspective(wl.frame((k[0] - 1) % 4, 1080, 1920, np.uint8), M, (1024, 1024), 1, nthreads=host_cores())))
     ok = ok and bool(np.allclose(buf["iou"].cpu().numpy(), co.rbox_iou(buf["dets_world"].cpu().numpy(), trks.cpu().numpy()[:, :5]), rtol=0, atol=1e-12))

@@ -105,15 +105,22 @@ __global__ __launch_bounds__(256) void project_points_kernel(const T* in, T* out
 // ---- rotated-rectangle IoU ------------------------------------------------------------------------
 // Area of (box A) n (box B) without clipping a vertex list.  In B's own frame B is the axis-aligned box |x| <= hx, |y| <= hy, and the map
 // C(x, y) = (clamp(x, -hx, hx), clamp(y, -hy, hy)) is the identity inside it and flattens everything outside onto its border (Jacobian 1
-// inside, 0 outside), so the area enclosed by the IMAGE C(dA) of A's outline is exactly area(A n B).  The image of a straight edge
-// p -> p + d is piecewise straight with corners only where the edge meets one of the four lines x = +-hx, y = +-hy: parameters
-// t = (+-hx - px) / dx, (+-hy - py) / dy.  So per edge: the four parameters, sorted and clamped to [0, 1]; the image points at 0, the four,
-// 1; five shoelace terms.  Every edge is independent of the others and the code is straight-line: no vertex lists in LDS, no branches, no
-// loop-carried chain -- the Sutherland-Hodgman walk this replaces (rounds 1-4; it is what oracle/warp_oracle.c still does) was a serial
-// chain of ~600 dependent float64 instructions that lasted 4 of the kernel's 8 us although only a few lanes of a wave ever ran it.
-// Robust by construction: a parameter that is wrong (dx ~ 0: reciprocal overflows to inf / NaN, the clamps turn it into 0 or 1) only adds
-// a corner ON the edge or misplaces a true one by no more than the edge's distance from that line, i.e. by rounding error; touching and
-// coincident edges need no tie rules.  Agreement with the oracle's clip: <= 1e-13 on the IoU (tests: 1e-12).
+// inside, 0 outside), so the area enclosed by the IMAGE C(dA) of A's outline is exactly area(A n B) = the contour integral of x~ dy~ along
+// it.  Along an edge p + t d, t in [0, 1], y~ moves (at the rate dy) only while y is inside the slab |y| < hy, i.e. for t in [b0, b1], and
+// x~ = clamp(px + t dx) is piecewise linear with corners where the edge meets x = +-hx, at t = a0 <= a1.  So the edge contributes
+//     dy * integral over [b0, b1] of clamp(px + t dx, -hx, hx) dt
+// = dy times three trapezoids over the nodes b0 <= a0' <= a1' <= b1 (the a's clamped into [b0, b1], the b's into [0, 1]).  Four independent
+// edges of ~40 float64 instructions, straight-line: no vertex lists in LDS, no branches, no loop-carried chain.  The Sutherland-Hodgman
+// walk this replaces (rounds 1-4; it is what oracle/warp_oracle.c still does) was a serial chain of ~600 float64 instructions that lasted
+// 4 of the kernel's 8 us although only a few lanes of a wave ever ran it -- one wave issues one float64 instruction per 4-8 cycles whatever
+// the number of active lanes, so the kernel's duration is the instruction count of this path.  (A first form, the symmetric shoelace sum over
+// the six image points of every edge with all four line parameters sorted, was 65 instructions per edge: 0.3 us more.  The edge loop rolled
+// into one copy of the code -- in case the cold instruction cache were the limit -- measured 1 us SLOWER: it is issue, not fetch.)
+// Robust by construction: a parameter that is wrong (dx ~ 0: the reciprocal overflows to inf / NaN, the clamps turn it into 0 or 1) only
+// puts a node ON the edge where no corner is, or misplaces a true corner by no more than the edge's distance from that line, i.e. by
+// rounding error; touching and coincident edges need no tie rules.  Against 50-digit arithmetic: <= 2e-15 on the IoU (1e-14 for crossing
+// 1000 : 1 slivers: the terms are of the order |edge of A| * hx; tests: 1e-13); the
+// oracle's float64 clip, which works in world coordinates, is itself only good to ulp(|centre|) / size (tests/test_oracle_iou.py).
 constexpr int kIouThreads = 64;
 __device__ __forceinline__ double rcp_full_of(double z) {
     double r = __builtin_amdgcn_rcp(z);
@@ -122,36 +129,68 @@ __device__ __forceinline__ double rcp_full_of(double z) {
     return r;
 }
 __device__ __forceinline__ double clamp_sym(double v, double h) { return fmin(fmax(v, -h), h); }
+
+// sin and cos of one angle below 2^20 in magnitude: x = n pi/2 + r with pi/2 in three float64 pieces (Cody-Waite, one fma each: |r| <= pi/4
+// to an absolute 2e-16), the two polynomial kernels of fdlibm (k_sin.c / k_cos.c coefficients), quadrant by n mod 4.  Absolute error
+// <= 3e-16 -- what a box corner needs; the library's sincos also keeps the RELATIVE error of a result near 0, and pays a double-double
+// reduction for it.  No branch inside, so two calls interleave (the library's pair ran one after the other: 1.6 us of the kernel's 6.5).
+__device__ __forceinline__ void sincos_reduced(double x, double& sn, double& cs) {
+    const double n = __builtin_rint(x * 0.6366197723675814);
+    double r = __builtin_fma(n, -1.5707963267948966, x);
+    r = __builtin_fma(n, -6.123233995736766e-17, r);
+    r = __builtin_fma(n, 1.4973849048591698e-33, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double sr = __builtin_fma(r * z, ps, r);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)n;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+// (sin, cos) of two angles at once; the library only for an angle of 2^20 and beyond, an infinity or a NaN
+__device__ __forceinline__ void sincos_pair(double x0, double x1, double& s0, double& c0, double& s1, double& c1) {
+    if (fabs(x0) < 1048576.0 && fabs(x1) < 1048576.0) {
+        sincos_reduced(x0, s0, c0);
+        sincos_reduced(x1, s1, c1);
+    } else {
+        sincos(x0, &s0, &c0);
+        sincos(x1, &s1, &c1);
+    }
+}
 // A: centre (lx, ly) in B's frame, half-length vector (ux, uy), half-width vector (vx, vy); B: half sizes hx (length, along x), hy.
 __device__ __forceinline__ double intersection_area(double lx, double ly, double ux, double uy, double vx, double vy, double hx, double hy) {
-    // corners, counter-clockwise from (-u - v), and their images
+    // corners, counter-clockwise from (-u - v); edges 0 / 2 run along +-2u, edges 1 / 3 along +-2v: four reciprocals serve the sixteen
+    // line parameters t = (+-h - p) / d = -p / d -+ h / |d|  (ordered as written)
     const double cx[4] = {lx - ux - vx, lx + ux - vx, lx + ux + vx, lx - ux + vx}, cy[4] = {ly - uy - vy, ly + uy - vy, ly + uy + vy, ly - uy + vy};
-    double Cx[4], Cy[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) Cx[k] = clamp_sym(cx[k], hx), Cy[k] = clamp_sym(cy[k], hy);
-    // edges 0 / 2 run along +-2u, edges 1 / 3 along +-2v: four reciprocals serve the sixteen parameters
-    const double iux = rcp_full_of(2.0 * ux), iuy = rcp_full_of(2.0 * uy), ivx = rcp_full_of(2.0 * vx), ivy = rcp_full_of(2.0 * vy);
+    const double dux = 2.0 * ux, duy = 2.0 * uy, dvx = 2.0 * vx, dvy = 2.0 * vy;
+    const double iux = rcp_full_of(dux), iuy = rcp_full_of(duy), ivx = rcp_full_of(dvx), ivy = rcp_full_of(dvy);
+    const double wux = hx * fabs(iux), wuy = hy * fabs(iuy), wvx = hx * fabs(ivx), wvy = hy * fabs(ivy);
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const double sgn = k < 2 ? 1.0 : -1.0;
-        const double dx = sgn * 2.0 * ((k & 1) ? vx : ux), dy = sgn * 2.0 * ((k & 1) ? vy : uy);
+        const double dx = sgn * ((k & 1) ? dvx : dux), dy = sgn * ((k & 1) ? dvy : duy);
         const double ix = sgn * ((k & 1) ? ivx : iux), iy = sgn * ((k & 1) ? ivy : iuy);
+        const double wx = (k & 1) ? wvx : wux, wy = (k & 1) ? wvy : wuy;
         const double px = cx[k], py = cy[k];
-        const double tx1 = (-hx - px) * ix, tx2 = (hx - px) * ix, ty1 = (-hy - py) * iy, ty2 = (hy - py) * iy;
-        // sorted (fmin / fmax return the other operand for a NaN), then clamped to the edge
-        const double a0 = fmin(tx1, tx2), a1 = fmax(tx1, tx2), b0 = fmin(ty1, ty2), b1 = fmax(ty1, ty2);
-        const double m1 = fmax(a0, b0), m2 = fmin(a1, b1);
-        const double t[4] = {fmin(fmax(fmin(a0, b0), 0.0), 1.0), fmin(fmax(fmin(m1, m2), 0.0), 1.0), fmin(fmax(fmax(m1, m2), 0.0), 1.0),
-                             fmin(fmax(fmax(a1, b1), 0.0), 1.0)};
-        double X0 = Cx[k], Y0 = Cy[k];
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const double X1 = i < 4 ? clamp_sym(__builtin_fma(t[i & 3], dx, px), hx) : Cx[(k + 1) & 3];
-            const double Y1 = i < 4 ? clamp_sym(__builtin_fma(t[i & 3], dy, py), hy) : Cy[(k + 1) & 3];
-            acc += __builtin_fma(X0, Y1, -(X1 * Y0));
-            X0 = X1, Y0 = Y1;
-        }
+        const double mx = -px * ix, my = -py * iy;
+        // (fmin / fmax return the other operand for a NaN: every parameter passes a clamp against finite bounds)
+        const double b0 = fmin(fmax(my - wy, 0.0), 1.0), b1 = fmin(fmax(my + wy, 0.0), 1.0);
+        const double a0 = fmin(fmax(mx - wx, b0), b1), a1 = fmin(fmax(mx + wx, b0), b1);
+        const double x0 = clamp_sym(__builtin_fma(b0, dx, px), hx), x1 = clamp_sym(__builtin_fma(a0, dx, px), hx);
+        const double x2 = clamp_sym(__builtin_fma(a1, dx, px), hx), x3 = clamp_sym(__builtin_fma(b1, dx, px), hx);
+        const double sum = __builtin_fma(x2 + x3, b1 - a1, __builtin_fma(x1 + x2, a1 - a0, (x0 + x1) * (a0 - b0)));
+        acc = __builtin_fma(dy, sum, acc);  // (twice the edge's integral: the trapezoids' 1 / 2 is applied once, below)
     }
     return fabs(0.5 * acc);
 }
@@ -160,20 +199,20 @@ __device__ __forceinline__ double intersection_area(double lx, double ly, double
 // circumscribed circles have diameters sqrt(w^2 + h^2), and ((da + db) / 2)^2 <= (da^2 + db^2) / 2, so centres further apart than that
 // bound belong to boxes that cannot intersect -- exactly 0 is returned for them.  In a tracker step almost every pair ends there (the 1e-4
 // margin keeps near-touching pairs on the exact path; NaNs fall through to it as well).  The lanes that remain turn A into B's frame
-// (`heading_a(c, s)` supplies the cosine and sine of A's heading only now: the tracker step derives them from the detection's direction
-// vector) and sum the contour.  Conventions of the oracle's clip that are kept: length h along the heading, width w across ("world",
+// (`heading_a(c, s)` turns the cosine and sine of `ayaw` into those of A's heading only now: the tracker step derives them from the
+// detection's direction vector) and sum the contour.  Conventions of the oracle's clip that are kept: length h along the heading, width w across ("world",
 // rbox.py:87-95); an intersection below 1e-14 of the boxes' area is the rounding noise of twenty signed terms of that order and reads as 0
 // (disjoint boxes give exactly 0, as they do there); a B with ONE negative size is a clockwise clip polygon there, which clips everything
 // away: 0.
 template <typename HeadingA>
-__device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, double aw, double ah, HeadingA&& heading_a, const double (&B)[5]) {
+__device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, double aw, double ah, double ayaw, HeadingA&& heading_a, const double (&B)[5]) {
     const double dx = acx - B[0], dy = acy - B[1];
     const double da2 = aw * aw + ah * ah, db2 = B[2] * B[2] + B[3] * B[3];
     const double area = fabs(aw * ah) + fabs(B[2] * B[3]);
     if (!valid || (dx * dx + dy * dy > 0.5 * (da2 + db2) * 1.0001 && area > 0)) return 0.0;
     double ca, sa, cb, sb;
-    heading_a(ca, sa);
-    sincos(B[4], &sb, &cb);
+    sincos_pair(ayaw, B[4], sa, ca, sb, cb);
+    heading_a(ca, sa);  // (in: cosine and sine of `ayaw`; out: of A's heading in B's world)
     const double cr = ca * cb + sa * sb, sr = sa * cb - ca * sb;  // A's heading relative to B's
     const double hxa = 0.5 * ah, hya = 0.5 * aw;
     double inter = intersection_area(cb * dx + sb * dy, cb * dy - sb * dx, cr * hxa, sr * hxa, -sr * hya, cr * hya, 0.5 * fabs(B[3]), 0.5 * fabs(B[2]));
@@ -185,14 +224,19 @@ __device__ __forceinline__ double pair_iou(bool valid, double acx, double acy, d
 template <typename T>
 __global__ __launch_bounds__(kIouThreads) void rbox_iou_kernel(const T* __restrict__ a, int na, int sa, const T* __restrict__ b, int nb, int sb,
                                                        T* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // column (box of b) -> coalesced stores
+    // (every scalar argument and all five numbers of box A -- the same in every lane -- are fetched up front, in one scalar-memory round trip
+    // each: left to the compiler they arrive one by one, each in front of its first use, A's yaw behind the rejection branch)
+    asm volatile("" ::"s"(a), "s"(na), "s"(sa), "s"(b), "s"(nb), "s"(sb), "s"(out));
+    const int j = blockIdx.x * kIouThreads + threadIdx.x;  // column (box of b) -> coalesced stores
     const int i = blockIdx.y;
     const bool valid = j < nb;
     const T* pa = a + (int64_t)i * sa;
     const T* pb = b + (int64_t)(valid ? j : 0) * sb;
-    const double A[5] = {(double)pa[0], (double)pa[1], (double)pa[2], (double)pa[3], (double)pa[4]};
+    const T a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4];
     const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
-    const double v = pair_iou(valid, A[0], A[1], A[2], A[3], [&](double& c, double& s_) { sincos(A[4], &s_, &c); }, B);
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4));
+    const double A[5] = {(double)a0, (double)a1, (double)a2, (double)a3, (double)a4};
+    const double v = pair_iou(valid, A[0], A[1], A[2], A[3], A[4], [](double&, double&) {}, B);
     if (valid) out[(int64_t)i * nb + j] = (T)v;
 }
 
@@ -240,6 +284,9 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
                                                                    const SimH Hwb, const H9 Him, int has_img, double thr, T* __restrict__ dets_world,
                                                                    T* __restrict__ iou, uint8_t* __restrict__ cand, T* __restrict__ dets_img) {
     const int tid = (int)threadIdx.x;
+    // Every scalar argument is wanted NOW: left alone, the compiler fetches each kernel argument right in front of its first use, behind
+    // the branches -- five scalar-memory round trips one after the other at the head of the scoring path.
+    asm volatile("" ::"s"(dets), "s"(trks), "s"(n), "s"(sd), "s"(m), "s"(st), "s"(has_img), "s"(thr), "s"(dets_world), "s"(iou), "s"(cand), "s"(dets_img));
     if ((int)blockIdx.y >= n) {
         // OUTPUT workgroups (rows n .. of the grid, column 0 only): lane l writes the world box and the image-plane centre of detection
         // 64 (blockIdx.y - n) + l.  The yaw's sincos + atan2 chain runs here, 64 detections at a time, beside the scoring workgroups --
@@ -260,22 +307,25 @@ __global__ __launch_bounds__(kIouThreads) void tracker_step_kernel(const T* __re
     }
     if (m <= 0) return;
     const int i = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + tid;
+    const int j = blockIdx.x * kIouThreads + tid;
     const bool valid = j < m;
     const T* pd = dets + (int64_t)i * sd;
+    const T* pb = trks + (int64_t)(valid ? j : 0) * st;
+    // the detection (the same five scalars in every lane: one scalar-memory fetch, yaw included -- read where the heading needs it, the
+    // yaw's fetch sat behind the rejection branch: a second round trip, 1.5 of the kernel's 8 us) and the lane's tracker box, side by side
+    const T d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3], d4 = pd[4];
+    const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
+    asm volatile("" ::"s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4));
     // centre and size of the detection in the world, as box_through computes them (every lane: the same scalars, no LDS round trip);
     // rounded to the storage type like the dets_world output -- the box the tracker would see
-    const double x = (double)pd[0], y = (double)pd[1];
+    const double x = (double)d0, y = (double)d1, det_yaw = (double)d4;
     const double X = Hwb.h[0] * x + Hwb.h[1] * y + Hwb.h[2], Y = Hwb.h[3] * x + Hwb.h[4] * y + Hwb.h[5], W = Hwb.h[6] * x + Hwb.h[7] * y + Hwb.h[8];
-    const double acx = (double)(T)(X / W), acy = (double)(T)(Y / W), aw = (double)(T)((double)pd[2] * Hwb.scale), ah = (double)(T)((double)pd[3] * Hwb.scale);
-    const T* pb = trks + (int64_t)(valid ? j : 0) * st;
-    const double B[5] = {(double)pb[0], (double)pb[1], (double)pb[2], (double)pb[3], (double)pb[4]};
-    const double v = pair_iou(valid, acx, acy, aw, ah, [&](double& c, double& s_) {
+    const double acx = (double)(T)(X / W), acy = (double)(T)(Y / W), aw = (double)(T)((double)d2 * Hwb.scale), ah = (double)(T)((double)d3 * Hwb.scale);
+    const double v = pair_iou(valid, acx, acy, aw, ah, det_yaw, [&](double& c, double& s_) {
         // The world heading of a BEV detection is the direction H gives its (sin yaw, cos yaw) vector (angle_world_bev, rbox.py:162-171):
         // its cosine and sine are that vector normalised -- no atan2 followed by a sincos of the result.  (For float32 boxes this is the
         // heading BEFORE the yaw is rounded to float32 for dets_world: 6e-8 rad, inside the 2e-6 the float32 IoU is compared at.)
-        double sn, cs;
-        sincos((double)pd[4], &sn, &cs);
+        const double sn = s_, cs = c;
         const double tx = Hwb.h[0] * sn + Hwb.h[1] * cs, ty = Hwb.h[3] * sn + Hwb.h[4] * cs;
         const double q = tx * tx + ty * ty;  // 1 / sqrt(q): the hardware estimate and two Newton steps (<= 2 ulp; a square root and a quotient cost four times that)
         double inv = __builtin_amdgcn_rsq(q);

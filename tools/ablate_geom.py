@@ -6,9 +6,13 @@
 Specs patch a COPY of bev_amd/csrc/geom_kernels.hip:
     wg256      256 lanes (4 waves) per workgroup instead of 64: a quarter of the workgroups to dispatch
     wg128      128 lanes per workgroup
-    noclip     (timing only) the clip returns after the corners: what is left is launch + loads + rejection + sincos + stores
+    noclip     (timing only) the contour sum returns after the corners and reciprocals: what is left is launch + loads + rejection + sincos + stores
     rejectall  (timing only) every pair ends at the rejection test: launch + loads + stores
     empty      (timing only) the scoring lanes store 0 without reading a box: the launch floor of this grid
+    outfirst   the tracker step's output workgroups take the first rows of the grid instead of the last
+    unroll4    the contour's edge loop unrolled (four copies of its code)
+    libsincos  the library's sincos instead of the kernel's own reduced pair
+    noout / nohead   (timing only) the output workgroups return at once / the detection's heading costs nothing
 """
 import os
 import subprocess
@@ -27,15 +31,25 @@ def patch(text, spec):
     if spec in ("wg256", "wg128"):
         rep("constexpr int kIouThreads = 64;", "constexpr int kIouThreads = %s;" % spec[2:])
     elif spec == "noclip":
-        rep("    int n = 4;\n#pragma unroll 1\n    for (int e = 0; e < 4 && n > 0; e++) {",
-            "    int n = 4;\n    { double acc = 0; for (int i = 0; i < 4; i++) acc += A.x[i] * B.y[i] - A.y[i] * B.x[i]; if (acc != 1.2345e300) return acc * 1e-300; }\n"
-            "#pragma unroll 1\n    for (int e = 0; e < 4 && n > 0; e++) {")
+        rep("    double acc = 0.0;\n", "    double acc = 0.0;\n    if (hx != 1.2345e300) return (Cx[0] * Cy[1] + Cx[2] * Cy[3] + ix * jy + iy * jx) * 1e-300;\n")
     elif spec == "rejectall":
         rep("&& area > 0)) return 0.0;", "&& area > 0) || area != 1.2345e300) return 0.0;")
     elif spec == "empty":
         rep("    const T* pa = a + (int64_t)i * sa;\n", "    if (na != 123456789) { if (valid) out[(int64_t)i * nb + j] = (T)0; return; }\n    const T* pa = a + (int64_t)i * sa;\n")
         rep("    const T* pd = dets + (int64_t)i * sd;\n", "    if (n != 123456789) { if (valid) { iou[(int64_t)i * m + j] = (T)0; cand[(int64_t)i * m + j] = 0; } return; }\n"
             "    const T* pd = dets + (int64_t)i * sd;\n")
+    elif spec == "outfirst":  # the output workgroups take the FIRST rows of the grid instead of the last
+        rep("    if ((int)blockIdx.y >= n) {", "    const int out_rows = (n + kIouThreads - 1) / kIouThreads;\n    if ((int)blockIdx.y < out_rows) {")
+        rep("        const int i = ((int)blockIdx.y - n) * kIouThreads + tid;", "        const int i = (int)blockIdx.y * kIouThreads + tid;")
+        rep("    const int i = blockIdx.y;\n    const int j = blockIdx.x * kIouThreads + tid;", "    const int i = (int)blockIdx.y - out_rows;\n    const int j = blockIdx.x * kIouThreads + tid;")
+    elif spec == "noout":  # (timing only) the output workgroups return at once
+        rep("        if (blockIdx.x != 0 || i >= n) return;", "        if (blockIdx.x != 0 || i >= n || n != 123456789) return;")
+    elif spec == "nohead":  # (timing only) the detection's heading is a constant: no sincos / rsq in front of the contour
+        rep("        double sn, cs;\n        sincos(det_yaw, &sn, &cs);\n        const double tx", "        double sn = 0.6, cs = 0.8;\n        const double tx")
+    elif spec == "unroll4":  # the four edges of the contour as four copies of the code (3.8 KB) instead of one loop body (1 KB)
+        rep("#pragma unroll 1\n    for (int k = 0; k < 4; k++) {\n        const double px = cx[0]", "#pragma unroll\n    for (int k = 0; k < 4; k++) {\n        const double px = cx[0]")
+    elif spec == "libsincos":  # the library's sincos for both angles, one after the other
+        rep("    if (fabs(x0) < 1048576.0 && fabs(x1) < 1048576.0) {", "    if (fabs(x0) < 0.0 && fabs(x1) < 1048576.0) {")
     else:
         raise SystemExit("unknown spec %r" % spec)
     return text

@@ -35,6 +35,7 @@ for dt in (torch.float64, torch.float32):
     buf = tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world)
     t1 = times(lambda: tracker_geometry_step(dets, trks, H_world_bev, 0.3, H_img_world, out=buf))
     io = torch.empty((512, 512), dtype=dt, device="cuda")
-    t2 = times(lambda: rbox_iou(dets, trks, out=io))
+    dw = buf["dets_world"].clone()  # (the same pairs as the step scores)
+    t2 = times(lambda: rbox_iou(dw, trks, out=io))
     print("%s: tracker step median %.1f us (min %.1f)   iou alone median %.1f us (min %.1f)   candidates %d" % (
         str(dt).split(".")[1], np.median(t1), t1.min(), np.median(t2), t2.min(), int(buf["candidates"].sum())))
