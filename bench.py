@@ -620,6 +620,57 @@ def composite_config(dev):
             "one_launch_equals_three_warps_plus_blend": same}
 
 
+def small_branch_config(dev):
+    """the reference's "small" branch (vis_homo.py:73-78,90-91) on the headline's batch -- 32 x 1080p uint8 frames resized to 852 x 480
+    (cv2.resize, INTER_LINEAR) and the small frames warped to 1024^2 (the reference's two steps, its pixels) against the fused one-pass form
+    (the resize folded into the homography: warp_perspective_resized).  HIP-event time per launch, source sets rotated past the Infinity Cache;
+    both forms checked against the oracle (first and last frame of a set)."""
+    from bev_amd import warp
+    from bev_amd.resize import resize
+    from tests import workloads as wl
+    B, SH, SW, NW, NH, D, nset = 32, 1080, 1920, 852, 480, 1024, 4
+    sets = [torch.from_numpy(np.stack([wl.frame(32 * s_ + i, SH, SW, np.uint8) for i in range(B)])).to(dev) for s_ in range(nset)]
+    small = [torch.empty((B, NH, NW, 3), dtype=torch.uint8, device=dev) for _ in range(nset)]
+    outs = [torch.empty((B, D, D, 3), dtype=torch.uint8, device=dev) for _ in range(nset)]
+    M_small = np.stack([wl.jitter_H(wl.keystone_H(NW, NH, D, D), i) for i in range(B)])
+    S = warp.resize_matrix((SW, SH), (NW, NH), False)
+    M_fused = np.stack([m @ S for m in M_small])
+    minv_small, minv_fused = warp.device_inverse(M_small, dev), warp.device_inverse(M_fused, dev)
+    k = [0]
+
+    def step(do_resize, do_small, do_fused):
+        def fn():
+            i = k[0] % nset
+            if do_resize:
+                resize(sets[i], (NW, NH), out=small[i])
+            if do_small:
+                warp.warp_perspective(small[i], None, (D, D), out=outs[i], M_inv_device=minv_small)
+            if do_fused:
+                warp.warp_perspective(sets[i], None, (D, D), out=outs[i], M_inv_device=minv_fused)
+            k[0] += 1
+        return fn
+
+    t_resize = event_times(step(True, False, False), 100, 10)
+    t_two = event_times(step(True, True, False), 100, 10)
+    i = (k[0] - 1) % nset
+    two_np = outs[i][[0, B - 1]].cpu().numpy()
+    t_fused = event_times(step(False, False, True), 100, 10)
+    j = (k[0] - 1) % nset
+    fused_np = outs[j][[0, B - 1]].cpu().numpy()
+    from oracle import cpu_oracle as co  # checker, after the timed launches
+    ok_two = ok_fused = True
+    for n_, f in enumerate((0, B - 1)):
+        src_i, src_j = wl.frame(32 * i + f, SH, SW, np.uint8), wl.frame(32 * j + f, SH, SW, np.uint8)
+        ok_two = ok_two and bool(np.array_equal(two_np[n_], co.warp_perspective(co.resize_linear_u8(src_i, (NW, NH)), M_small[f], (D, D), 1, nthreads=host_cores())))
+        ok_fused = ok_fused and bool(np.array_equal(fused_np[n_], co.warp_perspective(src_j, M_fused[f], (D, D), 1, nthreads=host_cores())))
+    rbytes = B * (SH * SW + NH * NW) * 3
+    return {"workload": "32 x 1920x1080 uint8 -> resize 852x480 -> warp 1024x1024 (two steps, the reference's pixels) vs one fused pass",
+            "resize_us": round(float(t_resize.mean()) * 1e6, 1), "resize_frac_of_8TBs": round(rbytes / float(t_resize.mean()) / 8e12, 3),
+            "two_step_us": round(float(t_two.mean()) * 1e6, 1), "fused_us": round(float(t_fused.mean()) * 1e6, 1),
+            "two_step_matches_oracle": ok_two, "fused_matches_oracle": ok_fused, "matches_oracle": ok_two and ok_fused,
+            "kernels": "resize_linear_u8_px4_kernel<3> + warp_rows<uint8,3,linear> | warp_rows<uint8,3,linear>"}
+
+
 def pipeline_config(dev):
     """PCIe-inclusive frames/s of 1080p -> 1024^2 uint8: one call at a time against the three-stream pipeline (never `value`)."""
     from bev_amd import warp
@@ -709,6 +760,10 @@ def summary_of(result):
     f3 = cfg.get("f3_composite", {})
     if "one_launch_us" in f3:
         out["f3_comp"] = [us(f3, "one_launch_back_to_back_us"), None, None, f3.get("one_launch_equals_three_warps_plus_blend")]
+    f1 = cfg.get("f1_small_branch", {})
+    if "two_step_us" in f1:
+        out["f1_two_step"] = [us(f1, "two_step_us"), None, None, f1.get("two_step_matches_oracle")]
+        out["f1_fused"] = [us(f1, "fused_us"), None, None, f1.get("fused_matches_oracle")]
     pc = cfg.get("pcie_pipeline", {})
     if "pipelined_ms_per_frame" in pc:
         out["pcie_frame"] = [r4(pc["pipelined_ms_per_frame"]), None, None, None]
@@ -796,7 +851,8 @@ def main():
     if world == 1 and not args.no_configs:
         cfg = {}
         for name, fn in (("configs[0]", lambda: config0(dev)), ("configs[2]", lambda: config2(dev)), ("configs[3]", lambda: config3(args, dev, shard.barrier)),
-                         ("configs[4]", lambda: config4(dev)), ("f3_composite", lambda: composite_config(dev)), ("pcie_pipeline", lambda: pipeline_config(dev))):
+                         ("configs[4]", lambda: config4(dev)), ("f3_composite", lambda: composite_config(dev)), ("f1_small_branch", lambda: small_branch_config(dev)),
+                         ("pcie_pipeline", lambda: pipeline_config(dev))):
             try:
                 cfg[name] = fn()
             except Exception as e:  # a failing side measurement must not lose the headline line

@@ -423,6 +423,65 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
     }
 }
 
+
+// The same arithmetic, four destination pixels per lane -- the form a batch of frames runs (32 x 1080p -> 852 x 480 is 199 MB in, 39 MB out:
+// HBM-bound, where the one-pixel kernel above issued twelve byte loads and three byte stores per pixel).  Per pixel and source row ONE
+// unaligned 8-byte load holds both taps (2 C <= 8 bytes from sx * C; global memory takes unaligned vector loads on gfx950, a window that
+// straddles a 64-byte line costs a second request), the lane's 4 C result bytes leave as C aligned dwords.  The host takes this kernel
+// only when every row of both images starts 4-byte aligned and a source row holds >= 8 bytes; a window that would end beyond its row (the
+// last columns: one-tap pixels) is fetched byte by byte, as are the <= 3 pixels of a ragged right edge.
+template <int C>
+__global__ __launch_bounds__(256) void resize_linear_u8_px4_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int src_h, int src_w, int dst_h, int dst_w,
+                                                                   int64_t src_fs, int64_t src_rs, int64_t dst_fs, int64_t dst_rs, double scale_x, double scale_y) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= dst_w) return;
+    const uint8_t* frame = src + (int64_t)blockIdx.z * src_fs;
+    uint8_t* d = dst + (int64_t)blockIdx.z * dst_fs + (int64_t)y * dst_rs + (int64_t)x0 * C;
+    int sy, b0, b1;
+    bool unused;
+    resize_axis(y, scale_y, src_h, false, sy, b0, b1, unused);
+    const uint8_t* r0 = frame + (int64_t)min(max(sy, 0), src_h - 1) * src_rs;
+    const uint8_t* r1 = frame + (int64_t)min(max(sy + 1, 0), src_h - 1) * src_rs;
+    const int row_bytes = src_w * C;
+    uint32_t word[C] = {};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (x0 + p < dst_w) {
+            int sx, a0, a1;
+            bool one;
+            resize_axis(x0 + p, scale_x, src_w, true, sx, a0, a1, one);
+            const int off = sx * C;
+            uint32_t t0[2 * C], t1[2 * C];  // both taps of both rows, channel by channel
+            if (off + 8 <= row_bytes) {
+                uint64_t w0, w1;
+                __builtin_memcpy(&w0, r0 + off, 8);
+                __builtin_memcpy(&w1, r1 + off, 8);
+#pragma unroll
+                for (int k = 0; k < 2 * C; k++) t0[k] = (uint32_t)(w0 >> (8 * k)) & 255u, t1[k] = (uint32_t)(w1 >> (8 * k)) & 255u;
+            } else {
+                const int right = one ? 0 : C;  // (never read beyond the row: a one-tap column takes its own pixel twice)
+#pragma unroll
+                for (int k = 0; k < C; k++) t0[k] = r0[off + k], t0[C + k] = r0[off + right + k], t1[k] = r1[off + k], t1[C + k] = r1[off + right + k];
+            }
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                const int h0 = one ? (int)t0[k] * 2048 : (int)t0[k] * a0 + (int)t0[C + k] * a1;
+                const int h1 = one ? (int)t1[k] * 2048 : (int)t1[k] * a0 + (int)t1[C + k] * a1;
+                const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255u;
+                const int byte = p * C + k;  // position among the lane's 4 C result bytes
+                word[byte >> 2] |= v << (8 * (byte & 3));
+            }
+        }
+    }
+    if (x0 + 4 <= dst_w) {
+        uint32_t* dw = reinterpret_cast<uint32_t*>(d);
+#pragma unroll
+        for (int k = 0; k < C; k++) dw[k] = word[k];
+    } else {
+        for (int i = 0; i < (dst_w - x0) * C; i++) d[i] = (uint8_t)(word[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
 }  // namespace
 
 hipError_t launch_composite(const uint8_t* bg, const uint8_t* fg, const uint8_t* mask, uint8_t* out, int64_t n, hipStream_t stream) {
@@ -479,6 +538,26 @@ hipError_t launch_resize_linear_u8(const uint8_t* src, uint8_t* dst, int batch, 
     // cv::resize: scale = 1 / ((double)dst / src) -- two roundings, not src / dst
     const double scale_x = 1.0 / ((double)dst_w / src_w), scale_y = 1.0 / ((double)dst_h / src_h);
     const int box2 = fabs(scale_x - 2.0) < 2.220446049250313e-16 && fabs(scale_y - 2.0) < 2.220446049250313e-16;
+    // four pixels per lane wherever the dword stores and the 8-byte tap windows are legal (see the kernel); the 2 x 2 box mean and odd layouts
+    // stay with the one-pixel kernel
+    const bool px4 = !box2 && (int64_t)src_w * channels >= 8 && ((uintptr_t)dst & 3) == 0 && (dst_rs & 3) == 0 && (dst_fs & 3) == 0;
+    if (px4) {
+        const dim3 block4(256), grid4((dst_w + 1023) / 1024, dst_h, batch);
+#define BEVWARP_RESIZE4_CASE(C)                                                                                                                            \
+    case C:                                                                                                                                               \
+        hipLaunchKernelGGL(resize_linear_u8_px4_kernel<C>, grid4, block4, 0, stream, src, dst, src_h, src_w, dst_h, dst_w, src_fs, src_rs, dst_fs, dst_rs, \
+                           scale_x, scale_y);                                                                                                             \
+        break;
+        switch (channels) {
+            BEVWARP_RESIZE4_CASE(1)
+            BEVWARP_RESIZE4_CASE(2)
+            BEVWARP_RESIZE4_CASE(3)
+            default:
+                BEVWARP_RESIZE4_CASE(4)
+        }
+#undef BEVWARP_RESIZE4_CASE
+        return hipGetLastError();
+    }
     const dim3 block(256), grid((dst_w + 255) / 256, dst_h, batch);
 #define BEVWARP_RESIZE_CASE(C)                                                                                                                         \
     case C:                                                                                                                                            \

@@ -433,3 +433,38 @@ def test_resize_random_shapes():
         img = rng.integers(0, 256, (sh, sw, c), dtype=np.uint8)
         got = resize(torch.from_numpy(img).cuda(), (dw, dh)).cpu().numpy()
         np.testing.assert_array_equal(got, co.resize_linear_u8(img, (dw, dh)), err_msg="%dx%dx%d -> %dx%d" % (sw, sh, c, dw, dh))
+
+
+@pytest.mark.gpu
+def test_resize_four_pixels_per_lane_kernel_corners():
+    """The batch form of bevwarp_resize (four destination pixels per lane, 8-byte tap windows, dword stores): every channel count, right edges of
+    0-3 pixels beyond the last full lane, one-tap columns at the end of a row (strong magnification keeps many of them), source rows of
+    exactly 8 bytes, a row-padded destination whose rows still start 4-byte aligned (fast kernel) and one whose rows do not (one-pixel
+    kernel), batches -- bit for bit against the oracle."""
+    from bev_amd.resize import resize
+    rng = np.random.default_rng(99)
+    cases = []
+    for c in (1, 2, 3, 4):
+        for dw in (4 * 37, 4 * 37 + 4 // np.gcd(4, c)):  # rows of dw * c bytes, multiples of 4: the fast kernel, full and ragged last lanes
+            cases.append((61, max(8 // c, 3) + int(rng.integers(0, 90)), c, 47, dw))
+        cases.append((33, (8 + c - 1) // c, c, 20, 64))      # a source row of 8 bytes (or the first count above it): magnification, one-tap columns
+        cases.append((50, 97, c, 31, 400))                    # 4 x magnification
+    for sh, sw, c, dh, dw in cases:
+        img = rng.integers(0, 256, (3, sh, sw, c), dtype=np.uint8)
+        got = resize(torch.from_numpy(img).cuda(), (dw, dh)).cpu().numpy()
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], co.resize_linear_u8(img[i], (dw, dh)).reshape(dh, dw, c), err_msg="%dx%dx%d -> %dx%d" % (sw, sh, c, dw, dh))
+    img = rng.integers(0, 256, (120, 213, 3), dtype=np.uint8)
+    exp = co.resize_linear_u8(img, (100, 56))
+    src_t = torch.from_numpy(img).cuda()
+    for pad in (4, 3):  # padded destination rows: 100 * 3 + 12 bytes apart (aligned: fast kernel), 100 * 3 + 9 (not: one-pixel kernel)
+        hold = torch.full((56, 100 + pad, 3), 9, dtype=torch.uint8, device="cuda")
+        view = hold[:, :100]
+        from bev_amd import _lib
+        import ctypes
+        st = _lib.load().bevwarp_resize(src_t.data_ptr(), view.data_ptr(), 1, 120, 213, 56, 100, 3, 120 * 213 * 3, 213 * 3, view.stride(0) * 56, view.stride(0),
+                                        _lib.U8, _lib.INTER_LINEAR, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(view.cpu().numpy(), exp)
+        assert (hold[:, 100:].cpu().numpy() == 9).all()  # the padding is not written
