@@ -178,7 +178,8 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     const int64_t resident = resident_workgroups(dtype, channels, interp);
     a.tile_h = rows_per_pass() * 4;
     while (a.tile_h > rows_per_pass() && per_row_of_tiles * ((dst_h + a.tile_h - 1) / a.tile_h) < resident) a.tile_h /= 2;
-    if (dtype == BEVWARP_U8 && per_row_of_tiles * ((dst_h + 23) / 24) >= 2 * resident) a.tile_h = 24;
+    const int tall = rows_per_pass() * 6;  // (24 rows)
+    if (dtype == BEVWARP_U8 && per_row_of_tiles * ((dst_h + tall - 1) / tall) >= 2 * resident) a.tile_h = tall;
     a.tiles_x = (dst_w + tw - 1) / tw;
     const int tiles_y = (dst_h + a.tile_h - 1) / a.tile_h;
     a.tiles_per_frame = a.tiles_x * tiles_y;
@@ -192,7 +193,7 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
     // one resident round of half-height workgroups at the end of launches of at least two rounds (tile_h / 2 stays a multiple
     // of 4); measured neutral to -2.5 % on footprints whose tiles cost alike, -8..-14 % on a perspective BEV from 12 frames up
     const int64_t round_per_xcd = resident / 8;
-    a.tail_split = (a.tile_h % 8 == 0 && chunk >= 2 * round_per_xcd) ? (int)round_per_xcd : 0;
+    a.tail_split = (a.tile_h % (2 * rows_per_pass()) == 0 && chunk >= 2 * round_per_xcd) ? (int)round_per_xcd : 0;
     a.tpf_magic = div_magic((uint64_t)chunk * 8, (uint32_t)a.tiles_per_frame);
     a.tx_magic = div_magic((uint64_t)a.tiles_per_frame, (uint32_t)a.tiles_x);
     a.bw0_magic = div_magic((uint64_t)dst_w + tw, (uint32_t)a.bw0);

@@ -66,7 +66,7 @@ int resident_workgroups(int dtype, int channels, int interp) {
         return n;
     }();
     (void)dtype, (void)channels, (void)interp;  // (every format is compiled for the same occupancy)
-    return cus * kWavesPerSimd;
+    return cus * kWavesPerSimd * (4 / kWaves);
 }
 
 hipError_t launch_warp(const WarpArgs& a, int dtype, int channels, int interp, hipStream_t stream) {

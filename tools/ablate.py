@@ -24,6 +24,8 @@ snippet):
     pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
     ntstore   the wide destination stores are non-temporal
     stsc1 / stsc01   the wide destination stores carry the sc1 / sc0 sc1 cache policy (write-through)
+    wg1 / wg2   workgroups of one / two waves instead of four (the host sizes tiles by rows_per_pass(): 6 / 12 rows of 8-bit pixels, 4 / 8 of float)
+    pf<N>     tile prefetch: every wave of a full-height unturned interior tile touches its share of the tile's source sectors (N byte loads per lane) before its first taps
     ring16 / ring4   the staged form's ring holds 16 / 4 source rows instead of 8
 Values stay live through `asm volatile` so that nothing upstream is dead code (guide, methodology rule 17)."""
 import os
@@ -37,6 +39,17 @@ FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-
 
 KERNEL_FILES = ("coords.h", "sample.h", "warp_rows.h", "rows_coords.inc", "rows_sample.inc", "rows_store.inc", "rows_tiles.inc", "rows_staged.inc", "rows_run.inc", "warp_kernels.h")
 UNITS = ("warp_kernels", "warp_u8_linear", "warp_u8_nearest", "warp_f32_linear", "warp_f32_nearest", "warp_composite")
+
+
+def apply_patch(files, path):
+    """A unified diff against bev_amd/csrc (kept under tools/patches: experiments that are not product code), applied to the copies."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for n, t in files.items():
+            open(os.path.join(d, n), "w").write(t)
+        subprocess.check_call(["patch", "-s", "-p3", "-d", d, "-i", path])
+        for n in files:
+            files[n] = open(os.path.join(d, n)).read()
 
 
 def patch(files, spec):
@@ -139,6 +152,11 @@ def patch(files, spec):
             "        const uint32_t fpx = (uint32_t)a.chunk / (uint32_t)a.tiles_per_frame, per_row = fpx * (uint32_t)a.tiles_x;\n"
             "        const uint32_t r = in_run / per_row, rem = in_run - r * per_row, f = rem / (uint32_t)a.tiles_x;\n"
             "        frame_idx = (blockIdx.x & 7u) * fpx + f;\n        t = r * (uint32_t)a.tiles_x + (rem - f * (uint32_t)a.tiles_x);\n    }\n")
+    elif spec in ("wg1", "wg2"):  # workgroups of one / two waves (tiles of 6 / 12 rows of 8-bit pixels): a finished wave's slot is refilled without waiting for three others
+        rep("constexpr int kWG = 256;", "constexpr int kWG = %d;" % (64 * int(spec[2:])))
+    elif spec.startswith("pf") and spec[2:].isdigit():  # tile prefetch: N byte loads per lane over the tile's source footprint (tools/patches/tile_prefetch.patch)
+        apply_patch(files, os.path.join(ROOT, "tools", "patches", "tile_prefetch.patch"))
+        rep("constexpr int kPrefetchLoads = 0; ", "constexpr int kPrefetchLoads = %s; " % spec[2:])
     elif spec == "waves5":  # every warp kernel compiled for five waves per SIMD (<= 96 VGPRs)
         rep("constexpr int kWavesPerSimd = 4;", "constexpr int kWavesPerSimd = 5;")
     elif spec == "waves3":  # three waves per SIMD (<= 168 VGPRs): room for a third tap set
