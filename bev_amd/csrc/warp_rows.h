@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     // cycles per wave instruction and 4-byte-aligned 12-byte ones at ~18 (tools/ubench_stream.hip).
     constexpr bool kAligned = sizeof(T) == 1 && C == 3 && INTERP == kLinear;
     constexpr int WINB = kAligned ? 12 : LOADB;  // bytes a FAST row loads per tap row
+    constexpr bool kPairable = kAligned && RS4 && NSRC == 1 && PPL == 4;  // (pair tiles: rows_sample.inc issue_p)
     constexpr int kM = kAligned ? 2 : 1;         // FAST: both ends inside by this many pixels (the aligned window starts
                                                  // up to 3 bytes early: never before its row)
     constexpr int TRW = 64 * PPL * (sizeof(T) == 1 ? 1 : C);  // dwords of a wave's transposition row

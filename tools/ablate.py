@@ -121,7 +121,7 @@ def patch(files, spec):
         rep("            tie = min(tie, min(lx[j] & F::kTieMask, ly[j] & F::kTieMask));\n", "")
         rep("            for (int j = 0; j < PPL; j++) tie = min(tie, min(S1[j] & F::kTieMask, S2[j] & F::kTieMask));\n", "            for (int j = 0; j < PPL; j++) tie |= S1[j] >> 31;\n")
     elif spec == "ownrow":  # interior tiles: row segments whatever the slant
-        rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = false && fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
+        rep("        if (!tile_affine) tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        if (false) tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
     elif spec == "fillall":  # every tile costs what an outside tile costs: the launch + prologue + store floor
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (true) {")
     elif spec == "edgefill":  # tiles the frame's edge crosses cost what outside tiles cost
@@ -129,7 +129,7 @@ def patch(files, spec):
     elif spec == "infill":  # interior tiles cost what outside tiles cost
         rep("    if (tile_out) {  // every pixel of the tile is the border value", "    if (tile_out || tile_in) {")
     elif spec == "ownblk":  # interior tiles: blocks whatever the slant
-        rep("        tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
+        rep("        if (!tile_affine) tile_slanted = fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >", "        if (true) tile_slanted = true || fmaxf(edge_slant(0, 1), edge_slant(2, 3)) >")
     elif spec == "ntstore":  # the wide destination stores non-temporal (rounds 2-3 measured them slower on every format)
         rep("    *p = v;\n}", "    __builtin_nontemporal_store(v, p);\n}")
     elif spec in ("pwfix", "pws5"):  # the producer's wave index: always wave 3 / rotating with the dispatch order divided by the CUs of an XCD
@@ -157,6 +157,16 @@ def patch(files, spec):
     elif spec.startswith("pf") and spec[2:].isdigit():  # tile prefetch: N byte loads per lane over the tile's source footprint (tools/patches/tile_prefetch.patch)
         apply_patch(files, os.path.join(ROOT, "tools", "patches", "tile_prefetch.patch"))
         rep("constexpr int kPrefetchLoads = 0; ", "constexpr int kPrefetchLoads = %s; " % spec[2:])
+    elif spec == "nosplit":  # no half-height workgroups at the end of an XCD's run (the extra workgroups of the grid leave at once)
+        rep("    if (seq >= (uint32_t)(a.chunk - a.tail_split)) {", "    if (seq >= (uint32_t)a.chunk) return;\n    if (false) {")
+    elif spec == "noclass":  # timing only, all-interior row-affine footprints (abx --homography inset): no tile classification -- every tile is taken for an interior pair tile
+        rep("    // -- the passes of this wave over the tile, in order.\n", "    tile_in = true, tile_out = false, tile_slanted = false, tile_affine = true, tile_pair = true;\n    // -- the passes of this wave over the tile, in order.\n")
+    elif spec == "w4x":  # exactly four waves per SIMD whatever the register count (with noclass, whose kernels shrink)
+        rep("amdgpu_waves_per_eu(NSRC > 1 ? 3 : kWavesPerSimd, 8)", "amdgpu_waves_per_eu(4, 4)")
+    elif spec == "nopair":  # no tile takes the pair loads (rows_tiles.inc: tile_pair)
+        rep("__ballot(stp >= 0.0 && stp <= 1.9375)", "__ballot(false)")
+    elif spec == "allpair":  # every row-affine interior tile takes them (timing / diagnosis only: wrong beyond 2 source pixels per pixel)
+        rep("__ballot(stp >= 0.0 && stp <= 1.9375)", "__ballot(true)")
     elif spec == "waves5":  # every warp kernel compiled for five waves per SIMD (<= 96 VGPRs)
         rep("constexpr int kWavesPerSimd = 4;", "constexpr int kWavesPerSimd = 5;")
     elif spec == "waves3":  # three waves per SIMD (<= 168 VGPRs): room for a third tap set

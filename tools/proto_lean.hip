@@ -28,7 +28,7 @@ struct LeanArgs {
 };
 
 template <int PPL, int ROWS, int AHEAD, int WPE, int MODE = 0, bool PAIR = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void warp_lean(const LeanArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, (MODE & 32) ? WPE : 8))) void warp_lean(const LeanArgs a) {
     constexpr int TW = 64 * PPL, TH = 4 * ROWS;
     using F = Fix<kLinear>;
     __shared__ __attribute__((aligned(16))) uint32_t s_tr[4][ROWS][TW];
@@ -202,6 +202,7 @@ static int launch(const LeanArgs& a0, hipStream_t st) {
 
 // variant = PPL * 1000 + ROWS * 100 + AHEAD * 10 + WPE (+ 10000 * MODE: ablations of 2628 -- 1 no stores, 2 no tap loads, 4 no blend,
 // (+ 1000000: PAIR -- one 16-byte load per pixel pair and row)
+// 32 exactly WPE waves per SIMD (the register allocator may otherwise reach more);
 // 8 taps from the first 64 KB of the frame, 16 stores into the first 8 rows of the frame; sums combine)
 extern "C" int proto_lean(int variant, const void* src, void* dst, const double* minv, int batch, int src_h, int src_w, int dst_h, int dst_w, long src_fs,
                           long src_rs, long dst_fs, long dst_rs, unsigned long long* ties, void* stream) {
@@ -234,12 +235,12 @@ extern "C" int proto_lean(int variant, const void* src, void* dst, const double*
 #define P(PP, R, A_, W, MODE) \
     case 1000000 + PP * 1000 + R * 100 + A_ * 10 + W + 10000 * MODE: \
         return launch<PP, R, A_, W, MODE, true>(a, st);
-        P(4, 6, 2, 4, 0) P(4, 6, 2, 5, 0) P(4, 6, 3, 4, 0) P(2, 6, 2, 8, 0) P(2, 6, 3, 8, 0) P(2, 6, 2, 6, 0) P(4, 6, 2, 5, 4) P(4, 6, 2, 5, 1) P(4, 6, 2, 5, 5) P(2, 6, 2, 8, 4) P(2, 6, 2, 8, 5)
+        P(4, 6, 2, 4, 32) P(4, 6, 2, 3, 32) P(4, 6, 2, 5, 32) P(4, 6, 2, 4, 0) P(4, 6, 2, 5, 0) P(4, 6, 3, 4, 0) P(2, 6, 2, 8, 0) P(2, 6, 3, 8, 0) P(2, 6, 2, 6, 0) P(4, 6, 2, 5, 4) P(4, 6, 2, 5, 1) P(4, 6, 2, 5, 5) P(2, 6, 2, 8, 4) P(2, 6, 2, 8, 5)
 #undef P
 #define A(MODE) \
     case 2628 + 10000 * MODE: \
         return launch<2, 6, 2, 8, MODE>(a, st);
-        A(1) A(2) A(3) A(4) A(5) A(6) A(7) A(8) A(9) A(16) A(18) A(24) A(20) A(22) A(12)
+        A(1) A(2) A(3) A(4) A(5) A(6) A(7) A(8) A(9) A(32) A(16) A(18) A(24) A(20) A(22) A(12)
 #undef A
     }
     return -2;
