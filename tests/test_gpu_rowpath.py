@@ -378,3 +378,49 @@ def test_row_affine_tiles_and_their_tolerance(W, dtype, interp):
     got = W.warp_perspective(torch.from_numpy(frames).cuda(), Ms, (dw, dh), flags=interp).cpu().numpy()
     for g in range(4):
         np.testing.assert_array_equal(got[g], co.warp_perspective(frames[g], Ms[g], (dw, dh), interp))
+
+
+@pytest.mark.parametrize("misalign", [0, 1, 2, 3])
+def test_pair_tiles_scales_mirrors_and_alignments(W, misalign):
+    """Row-affine interior tiles of 8-bit RGB whose left taps advance by 0 .. 2 source pixels per destination pixel fetch the taps of
+    two adjacent pixels with one 16-byte load (rows_sample.inc, issue_p / finish_p).  Horizontal scales from strong magnification up
+    to and across the 2 - 1/16 limit, mirrored maps (which must not take the path), a divide that changes the scale from the tile's
+    top row to its bottom row, ties -- through source views whose frames start 0 .. 3 bytes off a 4-byte boundary (row stride a
+    multiple of 4: the RS4 kernel) -- all must equal the oracle."""
+    sw, sh, dw, dh = 1020, 300, 512, 96
+    src = wl.frame(41 + misalign, sh, sw, np.uint8)
+    big = torch.zeros((sh, sw + 4, 3), dtype=torch.uint8, device="cuda")  # row stride 3072: a multiple of 4
+    lo = (misalign * 3) % 4  # the view starts `misalign` pixels in: 0 / 3 / 2 / 1 bytes off a 4-byte boundary
+    big[:, misalign:misalign + sw] = torch.from_numpy(src).cuda()
+    view = big[:, misalign:misalign + sw]
+    assert view.data_ptr() % 4 == lo and view.stride(0) % 4 == 0
+
+    def check(M):
+        out = torch.full((dh, dw, 3), 77, dtype=torch.uint8, device="cuda")
+        W.warp_perspective(view, M, (dw, dh), flags=1 | 16, out=out)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), co.warp_perspective(src, M, (dw, dh), 1, m_is_inverse=True))
+
+    for s in (0.3, 0.75, 1.0, 1.5, 1.875, 1.93, 1.9375, 1.94, 1.97):
+        check(np.array([[s, 0.0, 4.25], [0.0, 1.5, 30.0], [0.0, 0.0, 1.0]]))                       # pure scale: the same step on every row
+        check(np.array([[s, 0.0, 4.25 + 1 / 64], [0.0, 1.5, 30.0 + 1 / 64], [0.0, 0.0007, 1.0]]))  # keystone: the step shrinks down the tile, ties
+    check(np.array([[1.99, 0.0, 1.0], [0.0, 1.5, 30.0], [0.0, -0.0004, 1.0]]))                     # under the limit at the top, over it at the bottom
+    check(np.array([[-1.5, 0.0, 1000.0], [0.0, 1.5, 30.0], [0.0, 0.0, 1.0]]))                      # mirrored: left taps run backwards
+    check(np.array([[1.0, 0.0, 3.0], [0.0, 1.0, 5.0], [0.0, 0.0, 1.0]]))                           # integer shift: every pixel a tie
+    check(np.array([[1.875, 0.0, 0.0], [0.0, 2.0, 8.0], [0.0, 0.0, 1.0]]))                         # reaches the frame's first column
+
+
+def test_pair_tiles_full_height_batched(W):
+    """The same path in the straight-line form of full-height tiles (24 rows: launches of at least two resident rounds), and in the
+    half-height workgroups at the end of every XCD's run: 32 frames with per-frame keystones of different horizontal scales."""
+    sw, sh, dw, dh, B = 1000, 360, 512, 768, 32
+    rng = np.random.default_rng(5)
+    frames = np.stack([wl.frame(60 + g % 3, sh, sw, np.uint8) for g in range(B)])
+    Ms = []
+    for g in range(B):
+        s = rng.uniform(0.6, 1.93)
+        Ms.append(np.array([[s, 0.0, rng.uniform(2, 6)], [0.0, 0.44, rng.uniform(3, 9)], [0.0, rng.uniform(-1e-4, 1e-4), 1.0]]))
+    Ms = np.stack(Ms)
+    got = W.warp_perspective(torch.from_numpy(frames).cuda(), Ms, (dw, dh), flags=1 | 16).cpu().numpy()
+    for g in range(B):
+        np.testing.assert_array_equal(got[g], co.warp_perspective(frames[g], Ms[g], (dw, dh), 1, m_is_inverse=True))
