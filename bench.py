@@ -414,8 +414,10 @@ class Workload:
             if busy > hbm_share:  # the VALU is busier than the memory system is full: name it
                 r["bound"] = "valu-issue"
             r["hbm_share_of_streaming_ceiling"] = round(hbm_share, 3)
-            if max(busy, hbm_share) < 0.9:  # neither saturated: the kernel waits on its load path, not on a throughput limit
-                r["bound_detail"] = "VALU busy %.2f, HBM traffic at %.2f of the measured streaming rate: neither saturated -- load path / latency" % (busy, hbm_share)
+            if max(busy, hbm_share) < 0.9:  # neither saturated: say which is the busier and what else the time goes to
+                r["bound_detail"] = ("VALU busy %.2f, HBM traffic at %.2f of the measured streaming rate: neither saturated -- %s" %
+                                     (busy, hbm_share, "vector-instruction issue is the busiest unit (pair loads halved the gathers; the rest is per-tile set-up and waits)"
+                                      if busy > hbm_share else "the gather path (instructions in flight), not a throughput limit"))
         return r
 
 
