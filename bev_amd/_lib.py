@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("BEVWARP_LIB") or os.path.join(_CSRC, "libbevwarp.so")
 
 U8, F32, F64 = 0, 1, 2
 INTER_NEAREST, INTER_LINEAR = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/bevwarp.h declares: (name, restype, argtypes)
 _c = ctypes
@@ -24,6 +24,10 @@ SYMBOLS = {
     "bevwarp_warp": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                 _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                 _c.c_void_p, _c.c_void_p]),
+    "bevwarp_warp_classes": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
+    "bevwarp_tile_classes_bytes": (_c.c_int64, [_c.c_int] * 8),
     "bevwarp_warp_planar": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),

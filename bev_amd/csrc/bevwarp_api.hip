@@ -115,9 +115,10 @@ struct PlanarOut {  // bevwarp_warp_planar: float32 channel planes instead of in
 
 int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
               int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv,
-              int m_count, int dtype, int interp, const double* border_value, void* stream, const PlanarOut* po) {
+              int m_count, int dtype, int interp, const double* border_value, void* stream, const PlanarOut* po, void* classes = nullptr,
+              int classes_mode = 0, int64_t* classes_bytes = nullptr) {
     using namespace bevwarp;
-    if (!src || !dst || !M_inv) return BEVWARP_ERR_BAD_ARG;
+    if (!classes_bytes && (!src || !dst || !M_inv)) return BEVWARP_ERR_BAD_ARG;
     if (batch < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return BEVWARP_ERR_BAD_ARG;
     if (dtype != BEVWARP_U8 && dtype != BEVWARP_F32) return BEVWARP_ERR_UNSUPPORTED;
     if (interp != BEVWARP_NEAREST && interp != BEVWARP_LINEAR) return BEVWARP_ERR_UNSUPPORTED;
@@ -219,6 +220,17 @@ int warp_impl(const void* src, void* dst, int batch, int src_h, int src_w, int d
         const double r = nearbyint(b);  // saturate_cast<uchar>: round half to even, clamp
         a.bval_u8[k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
     }
+    if (classes_bytes) {  // (bevwarp_tile_classes_bytes: the table of this launch geometry -- full tile, upper half, lower half per tile)
+        *classes_bytes = 3 * a.total_tiles * (int64_t)sizeof(uint32_t);
+        return BEVWARP_OK;
+    }
+    if (classes) {
+        if ((uintptr_t)classes % 4) return BEVWARP_ERR_BAD_ARG;
+        if (classes_mode == BEVWARP_CLASSES_FILL)
+            a.classify_out = (uint32_t*)classes;
+        else
+            a.tile_class = (const uint32_t*)classes;
+    }
     const hipError_t e = launch_warp(a, dtype, channels, interp, (hipStream_t)stream);
     return e == hipSuccess ? BEVWARP_OK : hip_fail(e);
 }
@@ -231,6 +243,24 @@ int bevwarp_warp(const void* src, void* dst, int batch, int src_h, int src_w, in
                  int m_count, int dtype, int interp, const double* border_value, void* stream) {
     return warp_impl(src, dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride,
                      M_inv, m_count, dtype, interp, border_value, stream, nullptr);
+}
+
+int bevwarp_warp_classes(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int64_t src_frame_stride,
+                         int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride, const double* M_inv, int m_count, int dtype, int interp,
+                         const double* border_value, void* classes, int mode, void* stream) {
+    if (!classes || (mode != BEVWARP_CLASSES_USE && mode != BEVWARP_CLASSES_FILL)) return BEVWARP_ERR_BAD_ARG;
+    return warp_impl(src, dst, batch, src_h, src_w, dst_h, dst_w, channels, src_frame_stride, src_row_stride, dst_frame_stride, dst_row_stride,
+                     M_inv, m_count, dtype, interp, border_value, stream, nullptr, classes, mode);
+}
+
+int64_t bevwarp_tile_classes_bytes(int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int dtype, int interp) {
+    if (batch <= 0) return 0;
+    int64_t n = 0;
+    const int64_t esz = dtype == BEVWARP_U8 ? 1 : 4, srs = (int64_t)src_w * channels * esz, drs = (int64_t)dst_w * channels * esz;
+    // (the geometry depends on the sizes and the format only; the pointers are placeholders that pass the argument checks)
+    const int st = warp_impl((const void*)(uintptr_t)0x1000, (void*)(uintptr_t)0x700000000000ull, batch, src_h, src_w, dst_h, dst_w, channels, src_h * srs, srs, dst_h * drs, drs, (const double*)16, 1, dtype,
+                             interp, nullptr, nullptr, nullptr, nullptr, 0, &n);
+    return st == BEVWARP_OK ? n : (int64_t)st;
 }
 
 int bevwarp_warp_planar(const void* src, void* dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,

@@ -37,6 +37,9 @@ struct WarpArgs {
     int64_t xsrc_rs[2];
     int xsrc_h[2], xsrc_w[2];
     int fg_gray;                 // composite, bw_mode: source 1 (the foreground) is converted to grey tap by tap
+    // per-tile verdicts (bevwarp_warp_classes): entry 3 * item + (half + 1) = 0x80000000 | in | out << 1 | slanted << 2 | affine << 3 | pair << 4
+    const uint32_t* tile_class;  // read instead of classifying (entries without the top bit are classified as usual); NULL: classify
+    uint32_t* classify_out;      // fill mode: every workgroup writes its tile's verdict and leaves; NULL: warp
 };
 
 int tile_width(int dtype);   // destination pixels per row segment of one wave: 256 (8-bit) / 128 (float)

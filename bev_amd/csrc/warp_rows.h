@@ -142,6 +142,7 @@ __global__ __launch_bounds__(kWG * NSRC) __attribute__((amdgpu_waves_per_eu(NSRC
     if (in_run >= (uint32_t)a.chunk) in_run -= (uint32_t)a.chunk;
     const uint32_t item = (blockIdx.x & 7u) * (uint32_t)a.chunk + in_run;
     if (item >= (uint32_t)a.total_tiles) return;
+    const uint32_t cls_idx = item * 3u + (uint32_t)(half + 1);  // this workgroup's entry of the verdict table (full tile, upper half, lower half)
     const uint32_t frame_idx = fast_div(item, a.tpf_magic, (uint32_t)a.tiles_per_frame);
     const uint32_t t = item - frame_idx * (uint32_t)a.tiles_per_frame;
     const uint32_t ty = fast_div(t, a.tx_magic, (uint32_t)a.tiles_x), tx = t - ty * (uint32_t)a.tiles_x;

@@ -69,6 +69,7 @@ def device_inverse(M, device, inverse_given=False):
                                "before capturing, or pass M_inv_device")
         inv = Mh if inverse_given else invert_homography(Mh)
         hit = torch.from_numpy(inv).to(device)
+        hit._bevwarp_owned = True  # (cached by value, never written again: its tile verdicts may be cached too, _tile_classes)
         _minv_cache[key] = hit
         while len(_minv_cache) > _MINV_CACHE_MAX:
             _minv_cache.popitem(last=False)  # (safe: every use recorded its stream, see below)
@@ -119,6 +120,39 @@ def _border(border_value, C):
     return np.ascontiguousarray(np.broadcast_to(np.asarray(border_value, dtype=np.float64), (C,)))
 
 
+_CLASSES_MAX = 64
+_class_tables = collections.OrderedDict()  # (matrix tensor address, n matrices, batch, sizes, format) -> (verdict table, the matrix tensor)
+
+
+def _tile_classes(M_inv_device, n_m, call_args, stream):
+    """The per-tile verdict table (include/bevwarp.h, bevwarp_warp_classes) of a launch whose matrices are owned by device_inverse --
+    cached by value and never written again, so verdicts derived from them once hold for every later launch with the same geometry:
+    the camera loop of vis_homo.py:85-91 warps every frame of a video through one H_bev_img.  Filled on first use (one launch that
+    writes no pixel); None for matrices the caller owns (their contents may change under the same address), while a graph is being
+    captured (the fill would allocate), and for launches the library keeps no table for."""
+    if not getattr(M_inv_device, "_bevwarp_owned", False):
+        return None
+    (_, _, B, H, W, dh, dw, C, _, _, _, _, _, _, dtype, interp, _) = call_args
+    key = (M_inv_device.data_ptr(), n_m, B, H, W, dh, dw, C, dtype, interp)
+    hit = _class_tables.get(key)
+    if hit is not None:
+        _class_tables.move_to_end(key)
+        return hit[0]
+    with torch.cuda.device(M_inv_device.device):
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        lib = _lib.load()
+        nbytes = lib.bevwarp_tile_classes_bytes(B, H, W, dh, dw, C, dtype, interp)
+        if nbytes <= 0:
+            return None
+        table = torch.zeros(nbytes // 4, dtype=torch.int32, device=M_inv_device.device)
+        _lib.check(lib.bevwarp_warp_classes(*call_args, table.data_ptr(), 1, ctypes.c_void_p(stream)))
+    _class_tables[key] = (table, M_inv_device)  # (holding the matrix tensor keeps its address from being handed out again)
+    while len(_class_tables) > _CLASSES_MAX:
+        _class_tables.popitem(last=False)
+    return table
+
+
 def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=None, M_inv_device=None):
     """Batched perspective warp on the GPU.
 
@@ -142,7 +176,7 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
         except (AttributeError, TypeError, IndexError):
             plan = None
         if plan is not None:
-            fn, args, dev_index = plan
+            fn, args, dev_index = plan[:3]
             if torch.cuda.current_device() == dev_index:
                 st = fn(*args, _raw_stream(dev_index))
             else:
@@ -189,13 +223,17 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     args = (s4.data_ptr(), d4.data_ptr(), B, H, W, dh, dw, C, s4.stride(0) * esz, s4.stride(1) * esz, d4.stride(0) * esz, d4.stride(1) * esz,
             M_inv_device.data_ptr(), n_m, _DTYPES[s4.dtype], interp, None if bv is None else bv.ctypes.data_as(ctypes.c_void_p))
     fn = _lib.load().bevwarp_warp
+    table = _tile_classes(M_inv_device, n_m, args, stream)
+    if table is not None:  # verdicts of these very matrices and this geometry: the kernel reads them instead of deriving them
+        table.record_stream(torch.cuda.current_stream(s4.device))
+        fn, args = _lib.load().bevwarp_warp_classes, args + (table.data_ptr(), 0)
     with torch.cuda.device(s4.device):
         st = fn(*args, ctypes.c_void_p(stream))
     _lib.check(st)
     if key is not None and not copied:  # validated and launched: the next call with these very buffers skips the checks
         if len(_plans) >= _PLANS_MAX:
             _plans.clear()
-        _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device())
+        _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device(), table)  # (the plan keeps its verdict table alive)
     if out is not None:
         return out
     if len(shape) == 2:

@@ -7,6 +7,8 @@
  *
  *   bevwarp_warp            cv2.warpPerspective(img, H_bev_img, (u_size, v_size))
  *                             vis_homo.py:89, vis_homo.py:91, bev/tool/compo.py:38,46,47
+ *   bevwarp_warp_classes, bevwarp_tile_classes_bytes
+ *                           the same call inside a camera loop (one H_bev_img, every frame of the video): vis_homo.py:85-91
  *   bevwarp_invert_homography  the cv::invert(M) step inside that call (M is the forward src->dst map)
  *   bevwarp_warp_planar     the same warp (8-bit or float32 frames), written as normalised float32 channel planes in the same
  *                             pass (the layout step between vis_homo.py:89 and a detector's input;
@@ -47,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BEVWARP_ABI_VERSION 6
+#define BEVWARP_ABI_VERSION 7
 
 typedef enum bevwarp_status {
     BEVWARP_OK = 0,
@@ -99,6 +101,28 @@ int bevwarp_warp(const void *src, void *dst, int batch, int src_h, int src_w, in
                  int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride,
                  const double *M_inv, int m_count, int dtype, int interp, const double *border_value /*HOST*/,
                  void *stream);
+
+/*
+ * bevwarp_warp with the per-tile verdicts of an earlier launch (ABI v7).  Which way a tile is processed -- inside the frame, outside,
+ * cut by its edge; turned, rectification-form, pair loads -- follows from the matrices, the sizes and the format alone, and deriving it
+ * is a tenth of the 8-bit kernel's instructions.  A caller that warps many batches through the SAME matrices and geometry (a camera
+ * loop: cv2.warpPerspective per frame with one H_bev_img, vis_homo.py:85-91) fills a table once and hands it to every later call:
+ *
+ *   classes   device, bevwarp_tile_classes_bytes(...) bytes, 4-byte aligned.
+ *   mode      BEVWARP_CLASSES_FILL: write the verdicts, no pixel (src / dst are not accessed, but take the arguments of the warps
+ *                                   the table is meant for: the table is only valid for that batch, those sizes, strides' alignment,
+ *                                   format, interpolation and -- above all -- those M_inv CONTENTS);
+ *             BEVWARP_CLASSES_USE : warp, reading the verdicts.  Entries that were never filled are classified as usual.
+ * A table that does not belong to the matrices it is used with makes the kernel trust a wrong verdict (a tile taken for interior is
+ * sampled without guards): like a wrong pointer, that is the caller's to get right.  bevwarp_warp never needs a table.
+ */
+#define BEVWARP_CLASSES_USE 0
+#define BEVWARP_CLASSES_FILL 1
+int64_t bevwarp_tile_classes_bytes(int batch, int src_h, int src_w, int dst_h, int dst_w, int channels, int dtype, int interp);
+int bevwarp_warp_classes(const void *src, void *dst, int batch, int src_h, int src_w, int dst_h, int dst_w, int channels,
+                         int64_t src_frame_stride, int64_t src_row_stride, int64_t dst_frame_stride, int64_t dst_row_stride,
+                         const double *M_inv, int m_count, int dtype, int interp, const double *border_value /*HOST*/,
+                         void *classes, int mode, void *stream);
 
 /*
  * float32 PLANAR destination, one pass:

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert getattr(raw, n) is not None
-    assert lib.bevwarp_version() == _lib.ABI_VERSION == 6
+    assert lib.bevwarp_version() == _lib.ABI_VERSION == 7
 
 
 def test_header_cites_the_reference_interfaces():
@@ -85,6 +85,15 @@ def test_strerror_and_argument_validation_without_a_device(lib):
     assert call(a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=52, a8=384, a10=416, a16=nan_border) == -6  # different strides: conservative
     assert call(a2=3, a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=48, a8=384, a10=384, a16=nan_border) == -4  # batched, frame strides multiples of 48
     assert call(a2=3, a0=ctypes.c_void_p(base), a1=ctypes.c_void_p(base + 24), a9=48, a11=48, a8=400, a10=384, a16=nan_border) == -6
+    # verdict tables (ABI v7): their size follows the launch geometry; the call validates like bevwarp_warp plus its own two arguments
+    assert lib.bevwarp_tile_classes_bytes(32, 1080, 1920, 1024, 1024, 3, _lib.U8, 1) % 12 == 0 and lib.bevwarp_tile_classes_bytes(32, 1080, 1920, 1024, 1024, 3, _lib.U8, 1) > 0
+    assert lib.bevwarp_tile_classes_bytes(0, 8, 8, 8, 8, 3, _lib.U8, 1) == 0
+    assert lib.bevwarp_tile_classes_bytes(1, 8, 8, 8, 8, 5, _lib.U8, 1) == -2   # the status of the warp it describes
+    classes = lib.bevwarp_warp_classes
+    assert classes(*(ok_args[:17] + [None, 0, None])) == -1                     # no table
+    assert classes(*(ok_args[:17] + [one, 2, None])) == -1                      # unknown mode
+    assert classes(*(ok_args[:17] + [ctypes.c_void_p(18), 0, None])) == -1      # misaligned table
+    assert classes(*([None] + ok_args[1:17] + [one, 1, None])) == -1            # the warp's own checks still apply
     planar = lib.bevwarp_warp_planar
     pargs = [one, ctypes.c_void_p(16 + 100), 1, 8, 8, 8, 8, 3, 192, 24, 768, 256, 32, one, 1, _lib.U8, 1, None, None, None, None]
     assert planar(*pargs) == -6

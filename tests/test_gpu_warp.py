@@ -468,3 +468,62 @@ def test_resize_four_pixels_per_lane_kernel_corners():
         torch.cuda.synchronize()
         np.testing.assert_array_equal(view.cpu().numpy(), exp)
         assert (hold[:, 100:].cpu().numpy() == 9).all()  # the padding is not written
+
+
+def test_tile_verdict_tables_reproduce_the_plain_call():
+    """bevwarp_warp_classes (ABI v7): a table filled once for given matrices and geometry, then read by later launches instead of
+    classifying every tile again.  The filled launch writes no pixel; launches that use the table equal bevwarp_warp bit for bit --
+    keystone (pair tiles, edge-cut tiles), Brno-style (turned, outside tiles), 8-bit and float, both interpolations; entries that
+    were never filled fall back to classification; and the Python entry picks tables up by itself for matrices it owns."""
+    import ctypes
+    from bev_amd import _lib, warp
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for (B, sw, sh, dw, dh) in ((32, 640, 360, 512, 768), (3, 700, 420, 300, 77)):  # tall-tile launch with a split tail / a small one
+        for kind in ("keystone", "brno"):
+            base = (wl.keystone_H if kind == "keystone" else wl.synth_brno_H)(sw, sh, dw, dh)
+            Ms = np.stack([wl.jitter_H(base, g) for g in range(B)])
+            minv = warp.device_inverse(Ms, dev)
+            for tdt, ndt, dt, esz in ((torch.uint8, np.uint8, 0, 1), (torch.float32, np.float32, 1, 4)):
+                src = torch.stack([torch.from_numpy(wl.frame(70 + g % 3, sh, sw, ndt)) for g in range(B)]).to(dev)
+                for interp in (1, 0):
+                    n = lib.bevwarp_tile_classes_bytes(B, sh, sw, dh, dw, 3, dt, interp)
+                    assert n > 0 and n % 12 == 0
+                    table = torch.zeros(n // 4, dtype=torch.int32, device=dev)
+                    ref = torch.full((B, dh, dw, 3), 7, dtype=tdt, device=dev)
+                    got = torch.full((B, dh, dw, 3), 9, dtype=tdt, device=dev)
+                    args = lambda d: (src.data_ptr(), d.data_ptr(), B, sh, sw, dh, dw, 3, src.stride(0) * esz, src.stride(1) * esz, d.stride(0) * esz,
+                                      d.stride(1) * esz, minv.data_ptr(), B, dt, interp, None)
+                    assert lib.bevwarp_warp(*args(ref), ctypes.c_void_p(stream)) == 0
+                    assert lib.bevwarp_warp_classes(*args(got), table.data_ptr(), 1, ctypes.c_void_p(stream)) == 0  # fill: no pixel written
+                    torch.cuda.synchronize()
+                    assert bool((got == 9).all())
+                    t = table.cpu().numpy().view(np.uint32)
+                    assert ((t >> 31) == 1).sum() >= B * ((dw + 255) // 256)  # every launched workgroup left its verdict
+                    assert lib.bevwarp_warp_classes(*args(got), table.data_ptr(), 0, ctypes.c_void_p(stream)) == 0
+                    torch.cuda.synchronize()
+                    assert torch.equal(got, ref), (kind, dt, interp)
+                    # half the entries wiped: those tiles are classified as usual
+                    table[::2] = 0
+                    got.fill_(9)
+                    assert lib.bevwarp_warp_classes(*args(got), table.data_ptr(), 0, ctypes.c_void_p(stream)) == 0
+                    torch.cuda.synchronize()
+                    assert torch.equal(got, ref)
+    # the Python entry: matrices owned by device_inverse get a table on their first launch and use it from then on
+    warp._class_tables.clear()
+    sw, sh, dw, dh, B = 640, 360, 512, 96, 2
+    Ms = np.stack([wl.jitter_H(wl.keystone_H(sw, sh, dw, dh), g) for g in range(B)])
+    frames = np.stack([wl.frame(80 + g, sh, sw, np.uint8) for g in range(B)])
+    t = torch.from_numpy(frames).to(dev)
+    first = warp.warp_perspective(t, Ms, (dw, dh)).cpu().numpy()
+    assert len(warp._class_tables) == 1
+    second = warp.warp_perspective(t, Ms, (dw, dh)).cpu().numpy()
+    assert len(warp._class_tables) == 1
+    for g in range(B):
+        exp = co.warp_perspective(frames[g], Ms[g], (dw, dh), 1)
+        np.testing.assert_array_equal(first[g], exp)
+        np.testing.assert_array_equal(second[g], exp)
+    mine = warp.device_inverse(Ms, dev).clone()  # a tensor the caller owns: no table is kept for it
+    warp.warp_perspective(t, None, (dw, dh), M_inv_device=mine)
+    assert len(warp._class_tables) == 1
