@@ -300,7 +300,7 @@ def back_to_back_us(fn, n=500, warm=20):
 class Workload:
     """One dtype / interpolation variant of a batched warp resident on one GPU."""
 
-    def __init__(self, args, dtype, interp_name, rank, dev, planar=False, homography=None, device_frames=False):
+    def __init__(self, args, dtype, interp_name, rank, dev, planar=False, homography=None, device_frames=False, verdicts=False):
         from bev_amd import warp
         from tests import workloads as wl
         self.planar = planar  # float32 channel planes out (bevwarp_warp_planar, SURVEY.md 8(f2))
@@ -337,7 +337,11 @@ class Workload:
                         t[i] = self.srcs[0][(i + s) % B].flip(0) if s % 2 else self.srcs[0][(i + s) % B].flip(1)
             self.srcs.append(t)
             self.dsts.append(torch.empty((B, C, dh, dw), dtype=torch.float32, device=dev) if planar else torch.empty((B, dh, dw, C), dtype=tdtype, device=dev))
-        self.minv = warp.device_inverse(self.Ms, dev)
+        # The matrix tensor of the timed launches is the CALLER'S (a clone): every launch then classifies its tiles itself (bevwarp_warp).
+        # With `verdicts` it is the one device_inverse owns: the Python entry fills a per-tile verdict table on the first (warm-up)
+        # launch and the timed launches read it (bevwarp_warp_classes, ABI v7) -- a camera loop's steady state, reported as its own entry.
+        self.verdicts = verdicts
+        self.minv = warp.device_inverse(self.Ms, dev) if verdicts else warp.device_inverse(self.Ms, dev).clone()
         counts, touched = warp.footprint((sh, sw), self.Ms, (dw, dh), flags=self.interp, device=dev)
         self.footprint_px = int(counts.sum().item())
         # The same footprint at the granularity memory is fetched in: distinct 64-byte sectors / 128-byte lines of the source
@@ -379,7 +383,7 @@ class Workload:
     def roofline(self, launch_ms, ceiling=None, sclk_mhz=None):
         kernel_s = float(launch_ms.mean()) / 1e3
         achieved = self.algo_bytes / kernel_s / 1e9
-        rec = None if self.planar else load_profile(self.dtype, self.interp_name, self.homography, self.args)
+        rec = None if (self.planar or self.verdicts) else load_profile(self.dtype, self.interp_name, self.homography, self.args)  # (the committed profiles are of the plain launches)
         r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4),
              "traffic": None if rec is None else rec.get("hbm_bytes_per_launch"),
@@ -737,7 +741,7 @@ def summary_of(result):
                          "brno" if "brno" in result["config"]["workload"] else "key"): of_line(head)}
     for v in result.get("variants", []):
         name = "%s_%s_%s" % ("u8_planar" if "planar" in v["dtype"] else v["dtype"], "lin" if v["interp"] == "linear" else "near", hom[v["homography"]])
-        out[name] = of_line(v)
+        out[name + ("_tbl" if v.get("verdict_table") else "")] = of_line(v)
     cfg = result.get("configs", {})
 
     def us(d, key):
@@ -838,14 +842,16 @@ def main():
     if world == 1 and not args.no_variants:
         variants = []
         n = max(args.leg_steps, args.steps)
-        for dt, ip, planar, hom in (("u8", "linear", False, "keystone"), ("u8", "nearest", False, "keystone"), ("f32", "linear", False, "keystone"),
-                                    ("u8", "linear", True, "keystone"), ("u8", "linear", False, "brno"), ("f32", "linear", False, "brno"),
-                                    ("u8", "nearest", False, "brno")):
-            if (dt, ip, hom) == (args.dtype, args.interp, args.homography) and not planar:
+        for dt, ip, planar, hom, tbl in (("u8", "linear", False, "keystone", False), ("u8", "nearest", False, "keystone", False), ("f32", "linear", False, "keystone", False),
+                                         ("u8", "linear", True, "keystone", False), ("u8", "linear", False, "brno", False), ("f32", "linear", False, "brno", False),
+                                         ("u8", "nearest", False, "brno", False), ("u8", "linear", False, "keystone", True)):
+            if (dt, ip, hom) == (args.dtype, args.interp, args.homography) and not planar and not tbl:
                 continue
-            w = Workload(args, dt, ip, rank, dev, planar=planar, homography=hom, device_frames=True)
+            w = Workload(args, dt, ip, rank, dev, planar=planar, homography=hom, device_frames=True, verdicts=tbl)
             variants.append(variant_line(w, n, max(5, args.warmup // 2), shard.barrier, label=dt if not planar else "u8 -> f32 planar",
-                                         probe=not args.no_probe and not planar))
+                                         probe=not args.no_probe and not planar and not tbl))
+            if tbl:
+                variants[-1]["verdict_table"] = "per-tile verdicts of these matrices filled by one untimed launch, read by the timed ones (bevwarp_warp_classes)"
             del w
             torch.cuda.empty_cache()
         result["variants"] = variants

@@ -134,13 +134,13 @@ def _tile_classes(M_inv_device, n_m, call_args, stream):
         return None
     (_, _, B, H, W, dh, dw, C, _, _, _, _, _, _, dtype, interp, _) = call_args
     key = (M_inv_device.data_ptr(), n_m, B, H, W, dh, dw, C, dtype, interp)
-    hit = _class_tables.get(key)
-    if hit is not None:
-        _class_tables.move_to_end(key)
-        return hit[0]
     with torch.cuda.device(M_inv_device.device):
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():  # (a graph would replay the table's raw address: captured launches classify for themselves)
             return None
+        hit = _class_tables.get(key)
+        if hit is not None:
+            _class_tables.move_to_end(key)
+            return hit[0]
         lib = _lib.load()
         nbytes = lib.bevwarp_tile_classes_bytes(B, H, W, dh, dw, C, dtype, interp)
         if nbytes <= 0:
