@@ -742,6 +742,8 @@ def summary_of(result):
     for v in result.get("variants", []):
         name = "%s_%s_%s" % ("u8_planar" if "planar" in v["dtype"] else v["dtype"], "lin" if v["interp"] == "linear" else "near", hom[v["homography"]])
         out[name + ("_tbl" if v.get("verdict_table") else "")] = of_line(v)
+        if v.get("interleaved_us"):  # [plain us, table us] of launches interleaved on the same buffers
+            out[name + "_tbl_ab"] = [v["interleaved_us"].get("plain"), v["interleaved_us"].get("table")]
     cfg = result.get("configs", {})
 
     def us(d, key):
@@ -852,6 +854,20 @@ def main():
                                          probe=not args.no_probe and not planar and not tbl))
             if tbl:
                 variants[-1]["verdict_table"] = "per-tile verdicts of these matrices filled by one untimed launch, read by the timed ones (bevwarp_warp_classes)"
+                # entries of one run are minutes apart on a clock-managed chip: the table's own effect is read from launches INTERLEAVED on
+                # this workload's buffers, order drawn at random (plain = a clone of the matrix tensor, which the Python entry keeps no table for)
+                plain_m, rng_ab, t_ab = w.minv.clone(), np.random.default_rng(11), {"plain": [], "table": []}
+                for r_ab in range(2 * 60 + 6):
+                    which = "plain" if (r_ab < 6 and r_ab % 2) or (r_ab >= 6 and rng_ab.random() < 0.5) else "table"
+                    k_ab = int(rng_ab.integers(w.nsets))
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    w.warp.warp_perspective(w.srcs[k_ab], None, (w.dw, w.dh), flags=w.interp, out=w.dsts[k_ab], M_inv_device=plain_m if which == "plain" else w.minv)
+                    e1.record()
+                    e1.synchronize()
+                    if r_ab >= 6:
+                        t_ab[which].append(e0.elapsed_time(e1) * 1e3)
+                variants[-1]["interleaved_us"] = {k_: round(float(np.median(v_)), 1) for k_, v_ in t_ab.items()}
             del w
             torch.cuda.empty_cache()
         result["variants"] = variants
