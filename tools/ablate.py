@@ -24,6 +24,8 @@ snippet):
     pwfix / pws5   (with stage) the producer is always wave 3 / rotates with the dispatch order divided by the CUs of an XCD
     ntstore   the wide destination stores are non-temporal
     stsc1 / stsc01   the wide destination stores carry the sc1 / sc0 sc1 cache policy (write-through)
+    nopair / allpair   no tile / every row-affine interior tile takes the pair loads (rows_tiles.inc: tile_pair); nosplit: no half-height tail workgroups
+    noclass (+ w4x)   timing only, inset footprints: no tile classification (every tile an interior pair tile); w4x: exactly four waves per SIMD
     wg1 / wg2   workgroups of one / two waves instead of four (the host sizes tiles by rows_per_pass(): 6 / 12 rows of 8-bit pixels, 4 / 8 of float)
     pf<N>     tile prefetch: every wave of a full-height unturned interior tile touches its share of the tile's source sectors (N byte loads per lane) before its first taps
     ring16 / ring4   the staged form's ring holds 16 / 4 source rows instead of 8
