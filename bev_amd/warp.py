@@ -233,7 +233,9 @@ def warp_perspective(src, M, dsize, flags=INTER_LINEAR, border_value=None, out=N
     if key is not None and not copied:  # validated and launched: the next call with these very buffers skips the checks
         if len(_plans) >= _PLANS_MAX:
             _plans.clear()
-        _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device(), table)  # (the plan keeps its verdict table alive)
+        _plans[key] = (fn, args, s4.device.index if s4.device.index is not None else torch.cuda.current_device(), table,
+                       M_inv_device if table is not None else None)  # (a plan with a verdict table keeps the table AND the matrices it belongs to alive:
+        #                                                          their address must not be handed out again while the plan can be hit)
     if out is not None:
         return out
     if len(shape) == 2:
